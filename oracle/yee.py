@@ -1,0 +1,444 @@
+"""Oracle: Yee / Dey-Mittra operator assembly and the MxMagWaveOp matrices
+(TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py).
+
+numpy/scipy restatement, 3-D only, of
+
+  lattice / indices   src/MxGrid.h:96-128, src/MxGrid.cpp:171-193 (single rank:
+                      lb = 0, ub = N+1), src/MxGridDomain.cpp:21-89
+  field layouts       src/MxYeeMagFieldBase.cpp:85-116, src/MxYeeElecFieldBase.cpp:64-82,
+                      src/MxYeePsiField.cpp:50-70
+  BC translation      src/MxYeeMagFieldBase.cpp:119-168, src/MxYeeElecFieldBase.cpp:89-138,
+                      src/MxYeePsiField.cpp:73-96
+  map membership      src/MxGridField.cpp:41-77,256-297, src/MxYeeFitBField.cpp:63-80,
+                      src/MxYeeFitEField.cpp:53-88, src/MxYeePsiField.cpp:100-114
+  BC mirroring/phase  src/MxGridField.cpp:80-190 (incl. the two-'if' quirk at :101-116),
+                      src/MxYeeFitBField.cpp:83-90, src/MxYeeFitEField.cpp:91-98,
+                      src/MxYeePsiField.cpp:117-124
+  fractions           src/MxGridField.hpp:177-183, src/MxGridField.cpp:193-226
+  operators           src/MxYeeDeyMittraCurlE.cpp:117-179, CurlB.cpp:113-169,
+                      DivB.cpp:157-200, GradPsi.cpp:23-84, Fracs.cpp:30-131
+                      (minFrac arguments of src/MxEMOps.cpp:56-63,125-127 are all 0)
+  products            src/MxMagWaveOp.cpp:138-273, src/MxEMOps.h:61-74,
+                      src/MxUtil.cpp:318-371, src/MxCrsMatrix.cpp:84-116 (purgeZeros)
+
+Reference quirk kept in `strict` mode (the default): MxYeeFitEField::getCompFactor
+and MxYeePsiField::getCompFactor test useCompInMap on the *un-interiorised* cell
+(src/MxYeeFitEField.cpp:96, src/MxYeePsiField.cpp:122), so on a PERIODIC axis the
+wrap-around E entries of curlE at the upper boundary are dropped
+(src/MxGridField.cpp:70-73 returns false for cell == N, xi == 0).  A PEC cavity that
+does not touch the domain boundary (the pillbox) is unaffected.  `strict=False`
+evaluates membership on the interiorised cell instead, which restores
+curlE = curlB^T on periodic boxes and is what the periodic known-answer tests use.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import geometry as geo
+
+PERIODIC, ZERO, CONSTANT = 0, 1, 2
+
+
+def _bc(name):
+    return {"periodic": "periodic", "pec": "pec", "pmc": "pmc"}[name.lower()]
+
+
+class _Field:
+    def __init__(self, name, ncomp, coords, dirs):
+        self.name = name
+        self.ncomp = ncomp
+        self.coords = coords      # (ncomp, 3) cell-relative offsets in units of the cell size
+        self.dirs = dirs          # component direction (None for psi)
+        self.lbc = np.zeros((ncomp, 3), dtype=int)
+        self.ubc = np.zeros((ncomp, 3), dtype=int)
+        self.frac = None          # list over comps of ext-lattice arrays, or None (no region)
+        self.gids = None          # sorted global ids in the map
+        self.comp = None
+        self.cells = None
+
+
+class YeeSim:
+    """Single-rank 3-D restatement of MxEMSim::setup + MxEMOps + MxMagWaveOp::initMatrices."""
+
+    def __init__(self, N, origin=(0., 0., 0.), size=(1., 1., 1.),
+                 lower=("periodic",) * 3, upper=("periodic",) * 3,
+                 pec=None, phase_shifts=(0., 0., 0.), strict=True):
+        self.n = np.array([int(N)] * 3 if np.isscalar(N) else [int(x) for x in N])
+        self.origin = np.array(origin, dtype=float)
+        self.size = np.array(size, dtype=float)
+        self.d = self.size / self.n.astype(float)          # src/MxGrid.cpp:18
+        self.pec = pec
+        self.strict = strict
+        self.phase = np.exp(1j * np.array(phase_shifts, dtype=float))   # src/MxGridField.cpp:34-38
+        self.is_complex = bool(np.any(np.array(phase_shifts) != 0.0))
+        lower = [_bc(x) for x in lower]
+        upper = [_bc(x) for x in upper]
+
+        half = 0.5
+        B = _Field("bfield", 3, np.array([[0, half, half], [half, 0, half], [half, half, 0]]), [0, 1, 2])
+        E = _Field("efield", 3, np.array([[half, 0, 0], [0, half, 0], [0, 0, half]]), [0, 1, 2])
+        P = _Field("psifield", 1, np.array([[half, half, half]]), [None])
+        self.B, self.E, self.P = B, E, P
+        for F, normal_pec, tang_pec in ((B, ZERO, CONSTANT), (E, CONSTANT, ZERO)):
+            for c in range(3):
+                for i in range(3):
+                    for bcs, arr in ((lower, F.lbc), (upper, F.ubc)):
+                        if bcs[i] == "pec":
+                            arr[c, i] = normal_pec if F.dirs[c] == i else tang_pec
+                        elif bcs[i] == "pmc":
+                            arr[c, i] = tang_pec if F.dirs[c] == i else normal_pec
+                        else:
+                            arr[c, i] = PERIODIC
+        for i in range(3):
+            for bcs, arr in ((lower, P.lbc), (upper, P.ubc)):
+                arr[0, i] = {"pec": CONSTANT, "pmc": ZERO, "periodic": PERIODIC}[bcs[i]]
+
+        if pec is not None:
+            for F in (B, E, P):
+                self._add_shape_rep(F, pec)
+        for F in (B, E, P):
+            self._set_map(F)
+
+    # ---------------------------------------------------------------- lattice helpers
+    def node_coord(self, cells):
+        return self.origin + cells.astype(float) * self.d           # src/MxGrid.cpp:266-271
+
+    def cell_to_global(self, cells):
+        """src/MxGrid.h:98-113 (C order over the (N+1)^3 node lattice, wrap with N+1)."""
+        ni = self.n + 1
+        c = np.where(cells >= ni, cells - ni, np.where(cells < 0, ni + cells, cells))
+        return (c[..., 0] * ni[1] + c[..., 1]) * ni[2] + c[..., 2]
+
+    def global_to_cell(self, idx):
+        ni = self.n + 1
+        k = idx % ni[2]
+        j = (idx // ni[2]) % ni[1]
+        i = idx // (ni[2] * ni[1])
+        return np.stack([i, j, k], axis=-1)
+
+    def interior(self, F, comp, cells):
+        """getInteriorComp, src/MxGridField.cpp:80-142 (case 1 is a stand-alone `if`,
+        so case 2 overrides it for cell < 0)."""
+        new = cells.copy()
+        for i in range(3):
+            lbc, ubc = F.lbc[comp, i], F.ubc[comp, i]
+            xi0 = F.coords[comp, i] == 0.0
+            ci = cells[..., i]
+            ni = self.n[i]
+            out = ci.copy()
+            below = ci < 0
+            if lbc == PERIODIC:
+                out = np.where(below, ni + ci, out)
+            else:
+                out = np.where(below, -ci - 1, out)   # case 2 wins over case 1
+            if xi0:
+                on_ub = ci == ni
+                above = ci > ni
+                if ubc == PERIODIC:
+                    out = np.where(on_ub, 0, out)
+                    out = np.where(above, ci - ni, out)
+                else:
+                    out = np.where(above, ni - (ci - ni), out)
+            else:
+                above = ci >= ni
+                if ubc == PERIODIC:
+                    out = np.where(above, ci - ni, out)
+                else:
+                    out = np.where(above, ni - (ci - ni + 1), out)
+            new[..., i] = out
+        return new
+
+    def comp_coord(self, F, comp, cells):
+        return self.node_coord(cells) + F.coords[comp] * self.d
+
+    def frac_at(self, F, comp, cells):
+        """getCompFrac, src/MxGridField.hpp:258-277: one guard cell, 1.0 without a region."""
+        if F.frac is None:
+            return np.ones(cells.shape[:-1])
+        return F.frac[comp][cells[..., 0] + 1, cells[..., 1] + 1, cells[..., 2] + 1]
+
+    def _ext_cells(self):
+        ax = [np.arange(-1, self.n[i] + 2) for i in range(3)]
+        g = np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1)
+        return g.reshape(-1, 3)
+
+    def _add_shape_rep(self, F, shape):
+        """addShapeRep with one guard cell, src/MxGridField.cpp:193-226."""
+        cells = self._ext_cells()
+        ext_shape = tuple(self.n + 3)
+        F.frac = []
+        for comp in range(F.ncomp):
+            pos = self.comp_coord(F, comp, self.interior(F, comp, cells))
+            if F is self.B:
+                c1, c2 = (comp + 1) % 3, (comp + 2) % 3
+                fr = geo.rect_fractions(shape, pos, comp, self.d[c1], self.d[c2])
+            elif F is self.E:
+                fr = geo.segment_fractions(shape, pos, comp, self.d[comp])
+            else:
+                fr = geo.box_fractions(shape, pos, self.d[0], self.d[1], self.d[2])
+            F.frac.append(fr.reshape(ext_shape))
+
+    # ---------------------------------------------------------------- membership / factors
+    def base_use(self, F, comp, cells):
+        """MxGridField::useCompInMap, src/MxGridField.cpp:41-77."""
+        ok = np.ones(cells.shape[:-1], dtype=bool)
+        if F.frac is not None:
+            ok &= self.frac_at(F, comp, cells) != 0.0
+        for i in range(3):
+            ci = cells[..., i]
+            xi0 = F.coords[comp, i] == 0.0
+            ni = self.n[i]
+            if xi0:
+                if F.lbc[comp, i] == ZERO:
+                    ok &= ~(ci == 0)
+                if F.ubc[comp, i] in (ZERO, PERIODIC):
+                    ok &= ~(ci == ni)
+            else:
+                ok &= ~(ci == ni)
+        return ok
+
+    def b_use(self, cells):
+        """MxYeeFitBField::useCompInMap, src/MxYeeFitBField.cpp:63-80: any used
+        component keeps the whole cell (the dmFrac test is unreachable with dmFrac 0)."""
+        u = self.base_use(self.B, 0, cells)
+        for c in (1, 2):
+            u = u | self.base_use(self.B, c, cells)
+        return u
+
+    def e_use(self, comp, cells):
+        """MxYeeFitEField::useCompInMap, src/MxYeeFitEField.cpp:53-88."""
+        u = self.base_use(self.E, comp, cells)
+        c2, c3 = (comp + 1) % 3, (comp + 2) % 3
+        m3 = cells.copy(); m3[..., c3] -= 1
+        m2 = cells.copy(); m2[..., c2] -= 1
+        return u & self.b_use(cells) & self.b_use(m3) & self.b_use(m2)
+
+    def psi_use(self, cells):
+        """MxYeePsiField::useCompInMap, src/MxYeePsiField.cpp:100-114."""
+        u = self.base_use(self.P, 0, cells)
+        anyb = self.b_use(cells)
+        for i in range(3):
+            p = cells.copy(); p[..., i] += 1
+            anyb = anyb | self.b_use(p)
+        return u & anyb
+
+    def use(self, F, comp, cells):
+        if F is self.B:
+            return self.b_use(cells)
+        if F is self.E:
+            return self.e_use(comp, cells)
+        return self.psi_use(cells)
+
+    def base_factor(self, F, comp, cells):
+        """MxGridField::getCompFactor, src/MxGridField.cpp:145-190."""
+        res = np.ones(cells.shape[:-1], dtype=complex)
+        if F.frac is not None:
+            res = np.where(self.frac_at(F, comp, cells) == 0.0, 0.0, res)
+        for i in range(3):
+            ci = cells[..., i]
+            lbc, ubc = F.lbc[comp, i], F.ubc[comp, i]
+            xi0 = F.coords[comp, i] == 0.0
+            ni = self.n[i]
+            below = ci < 0
+            if lbc == PERIODIC:
+                res = np.where(below, res / self.phase[i], res)
+            elif lbc == ZERO:
+                res = np.where(below, -res, res)
+            if xi0:
+                if lbc == ZERO:
+                    res = np.where(ci == 0, 0.0, res)
+                on_ub = ci == ni
+                if ubc == PERIODIC:
+                    res = np.where(on_ub, res * self.phase[i], res)
+                elif ubc == ZERO:
+                    res = np.where(on_ub, 0.0, res)
+                above = ci > ni
+            else:
+                above = ci >= ni
+            if ubc == PERIODIC:
+                res = np.where(above, res * self.phase[i], res)
+            elif ubc == ZERO:
+                res = np.where(above, -res, res)
+        return res
+
+    def factor(self, F, comp, cells):
+        res = self.base_factor(F, comp, cells)
+        if F is self.B:
+            return res
+        probe = cells if self.strict else self.interior(F, comp, cells)
+        return np.where(self.use(F, comp, probe), res, 0.0)
+
+    def gid(self, F, comp, cells):
+        """globCompIndx, src/MxGridField.hpp:142-145."""
+        return comp + F.ncomp * self.cell_to_global(self.interior(F, comp, cells))
+
+    # ---------------------------------------------------------------- maps
+    def _set_map(self, F):
+        """setMap, src/MxGridField.cpp:256-297: interior cells in C order, comps inner."""
+        ax = [np.arange(0, self.n[i] + 1) for i in range(3)]
+        cells = np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1).reshape(-1, 3)
+        keep = np.stack([self.use(F, c, cells) for c in range(F.ncomp)], axis=1)   # (ncell, ncomp)
+        cell_idx, comp = np.nonzero(keep)
+        F.comp = comp
+        F.cells = cells[cell_idx]
+        F.gids = comp + F.ncomp * self.cell_to_global(F.cells)
+        assert np.all(np.diff(F.gids) > 0)
+
+    def lid(self, F, gids):
+        pos = np.searchsorted(F.gids, gids)
+        pos = np.clip(pos, 0, len(F.gids) - 1)
+        ok = F.gids[pos] == gids
+        return pos, ok
+
+    # ---------------------------------------------------------------- operators
+    def _assemble(self, rowF, colF, rows, entries):
+        """entries: list of (col_comp, col_cells, value arrays).  Zero factors are
+        dropped before insertion exactly like the reference's `if (factors[i] != 0)`."""
+        r_all, c_all, v_all = [], [], []
+        for row_lid, col_comp, col_cells, vals in entries:
+            fac = self.factor(colF, col_comp, col_cells)
+            nz = fac != 0
+            g = self.gid(colF, col_comp, col_cells[nz])
+            pos, ok = self.lid(colF, g)
+            if not np.all(ok):
+                raise AssertionError("column outside the domain map in %s x %s" % (rowF.name, colF.name))
+            r_all.append(row_lid[nz]); c_all.append(pos); v_all.append((fac[nz] * vals))
+        r = np.concatenate(r_all); c = np.concatenate(c_all); v = np.concatenate(v_all)
+        if not self.is_complex:
+            v = v.real
+        m = sp.coo_matrix((v, (r, c)), shape=(len(rowF.gids), len(colF.gids))).tocsr()
+        m.sum_duplicates()
+        m.sort_indices()
+        return m
+
+    def curlE(self):
+        """src/MxYeeDeyMittraCurlE.cpp:117-179 (rows: B map, cols: E map)."""
+        inv = 1.0 / self.d
+        entries = []
+        for c0 in range(3):
+            c1, c2 = (c0 + 1) % 3, (c0 + 2) % 3
+            sel = np.nonzero(self.B.comp == c0)[0]
+            cells = self.B.cells[sel]
+            live = self.factor(self.B, c0, cells) != 0          # :148-150
+            sel, cells = sel[live], cells[live]
+            p1 = cells.copy(); p1[:, c1] += 1
+            p2 = cells.copy(); p2[:, c2] += 1
+            entries += [(sel, c2, p1, inv[c1]), (sel, c2, cells, -inv[c1]),
+                        (sel, c1, p2, -inv[c2]), (sel, c1, cells, inv[c2])]
+        return self._assemble(self.B, self.E, None, entries)
+
+    def curlB(self):
+        """src/MxYeeDeyMittraCurlB.cpp:113-169 (rows: E map, cols: B map)."""
+        inv = 1.0 / self.d
+        entries = []
+        for c0 in range(3):
+            c1, c2 = (c0 + 1) % 3, (c0 + 2) % 3
+            sel = np.nonzero(self.E.comp == c0)[0]
+            cells = self.E.cells[sel]
+            m1 = cells.copy(); m1[:, c1] -= 1
+            m2 = cells.copy(); m2[:, c2] -= 1
+            entries += [(sel, c2, cells, inv[c1]), (sel, c2, m1, -inv[c1]),
+                        (sel, c1, cells, -inv[c2]), (sel, c1, m2, inv[c2])]
+        return self._assemble(self.E, self.B, None, entries)
+
+    def divB(self):
+        """src/MxYeeDeyMittraDivB.cpp:157-200 (rows: Psi map, cols: B map)."""
+        inv = 1.0 / self.d
+        sel = np.arange(len(self.P.gids))
+        cells = self.P.cells
+        entries = []
+        for c in range(3):
+            p = cells.copy(); p[:, c] += 1
+            entries += [(sel, c, p, inv[c]), (sel, c, cells, -inv[c])]
+        return self._assemble(self.P, self.B, None, entries)
+
+    def gradPsi(self):
+        """src/MxYeeDeyMittraGradPsi.cpp:23-84 (rows: B map, cols: Psi map)."""
+        inv = 1.0 / self.d
+        entries = []
+        for c in range(3):
+            sel = np.nonzero(self.B.comp == c)[0]
+            cells = self.B.cells[sel]
+            live = self.factor(self.B, c, cells) != 0           # :58-60
+            sel, cells = sel[live], cells[live]
+            m = cells.copy(); m[:, c] -= 1
+            entries += [(sel, 0, cells, inv[c]), (sel, 0, m, -inv[c])]
+        return self._assemble(self.B, self.P, None, entries)
+
+    def fracs(self, F, inverse=False):
+        """src/MxYeeDeyMittraFracs.cpp:30-131 with minFrac = 0: diagonal of the map's
+        fractions, or their reciprocals (0 stays 0)."""
+        v = self._frac_vec(F)
+        if inverse:
+            v = np.where(v == 0.0, 0.0, 1.0 / np.where(v == 0.0, 1.0, v))
+        if self.is_complex:
+            v = v.astype(complex)
+        return sp.diags(v, format="csr")
+
+    def _frac_vec(self, F):
+        out = np.empty(len(F.gids))
+        for c in range(F.ncomp):
+            s = F.comp == c
+            out[s] = self.frac_at(F, c, F.cells[s])
+        return out
+
+    # ---------------------------------------------------------------- MxMagWaveOp matrices
+    def single_ops(self):
+        """MxEMOps::setSingleOps, src/MxEMOps.cpp:39-168 (vacuum / PEC subset)."""
+        ops = {"curlE": self.curlE(), "curlB": self.curlB(),
+               "divB": self.divB(), "gradPsi": self.gradPsi()}
+        if self.pec is not None:
+            ops["dmA"] = self.fracs(self.B)
+            ops["dmL"] = self.fracs(self.E)
+            ops["dmVInv"] = self.fracs(self.P, inverse=True)
+        return ops
+
+    def wave_ops(self):
+        """MxMagWaveOp::initMatrices, src/MxMagWaveOp.cpp:138-245.  multiplyOps applies the
+        first name first (src/MxEMOps.h:61-66), i.e. the product is last * ... * first."""
+        o = self.single_ops()
+        has_pec = self.pec is not None
+        if has_pec:
+            curlcurl = o["curlE"] @ o["dmL"] @ o["curlB"]                       # :145-153
+            graddiv = o["dmA"] @ o["gradPsi"] @ o["dmVInv"] @ o["divB"] @ o["dmA"]   # :156-179
+            scalapl = -(o["divB"] @ o["dmA"] @ o["gradPsi"])                   # :208-220
+            rhs = o["dmA"]                                                      # :233-236
+        else:
+            curlcurl = o["curlE"] @ o["curlB"]
+            graddiv = o["gradPsi"] @ o["divB"]
+            scalapl = -(o["divB"] @ o["gradPsi"])
+            rhs = sp.identity(len(self.B.gids), format="csr",
+                              dtype=complex if self.is_complex else float)     # :240-241
+        veclapl = purge_zeros((curlcurl - graddiv).tocsr())                     # :183-193
+        for m in (curlcurl, graddiv, scalapl):
+            m.sort_indices()
+        o.update(curlCurl=curlcurl.tocsr(), gradDiv=graddiv.tocsr(), vecLapl=veclapl,
+                 scaLapl=scalapl.tocsr(), mRhs=rhs.tocsr())
+        return o
+
+
+def purge_zeros(m, tol=1.e-12):
+    """MxCrsMatrix::purgeZeros, src/MxCrsMatrix.cpp:84-116: keep |a| > 1e-12."""
+    m = m.tocsr().copy()
+    m.sum_duplicates()
+    m.data[np.abs(m.data) <= tol] = 0.0
+    m.eliminate_zeros()
+    m.sort_indices()
+    return m
+
+
+def shifted(veclapl, rhs, shift):
+    """MxMagWaveOp::setShift, src/MxMagWaveOp.cpp:248-255: vecLapl - shift * mRhs."""
+    m = (veclapl - shift * rhs).tocsr()
+    m.sum_duplicates()
+    m.sort_indices()
+    return m
+
+
+def default_shift(size):
+    """src/mx.py:711-712."""
+    return 0.05 * (2.0 * np.pi / max(size)) ** 2
+
+
+def pillbox_sim(N, **kw):
+    """Config 1/2/4 input: example/pillbox.py with resolution N (unit box at -0.5)."""
+    return YeeSim(N, origin=(-0.5,) * 3, size=(1.0,) * 3, pec=geo.pillbox(0.4, 0.8), **kw)
