@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MxMagWaveOp SpMV bandwidth + eigenpairs/s on the pillbox cavity.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one application of the shifted vector Laplacian (vecLapl - shift*dmA, the matrix
+every inner Krylov iteration of MxMagWaveOp::Apply multiplies with) to one block of vectors
+resident in HBM.  N = 1: example/pillbox.py geometry at 256^3 Yee cells (BASELINE.json configs[1]).
+N > 1: one GPU per MxGridDomain sub-box, weak scaling (every rank owns a 256^3-cell box).
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (HIP-event timed, against
+the 8 TB/s HBM3E peak, algorithmic bytes of SURVEY 8d) and `cpu_baseline` (the oracle's plain-C
+row loop on the same matrix, on the host cores of this box).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--n", type=int, default=256, help="Yee cells per side (per GPU)")
+    p.add_argument("--k", type=int, default=1, help="vectors in the block (SpMM when > 1)")
+    p.add_argument("--kernel", type=int, default=0)
+    p.add_argument("--eig-n", type=int, default=96, help="grid of the eigenpairs/s measurement (0 = skip)")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
+    return p.parse_args()
+
+
+def cpu_baseline(sim, shift, nrows, alg_bytes, budget):
+    """Oracle row loop (port of Epetra's serial CSR loop) on the SAME matrix, host cores of this box."""
+    from oracle import cref
+    nr, nc, nz, rp, ci, va = sim.op_raw("vecLapl", shift=shift)
+    x = np.random.default_rng(1).uniform(-1, 1, nc)
+    y = np.zeros(nr)
+    rp_v, ci_v, va_v = C.cast(rp, C.c_void_p), C.cast(ci, C.c_void_p), C.cast(va, C.c_void_p)
+    threads = cref.lib().oracle_num_threads()
+    cref.spmv_raw(nr, rp_v, ci_v, va_v, x, y, threads=True)      # warm-up / first touch
+    t0 = time.perf_counter(); cref.spmv_raw(nr, rp_v, ci_v, va_v, x, y, threads=False)
+    serial = time.perf_counter() - t0
+    reps, tsum = 0, 0.0
+    while tsum < max(budget - 2.0 * serial, 1.0) and reps < 200:
+        t0 = time.perf_counter(); cref.spmv_raw(nr, rp_v, ci_v, va_v, x, y, threads=True)
+        tsum += time.perf_counter() - t0; reps += 1
+    par = tsum / reps
+    return {"value": round(alg_bytes / par / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": "same %d-row matrix, %d applications of oracle/spmv_ref.c (OpenMP static rows); "
+                      "serial row loop: %.3f GB/s" % (nr, reps, alg_bytes / serial / 1e9),
+            "serial_value": round(alg_bytes / serial / 1e9, 3)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("WARNING: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    import maxwell_amd as mx
+
+    dist = None
+    uid = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.barrier()
+        buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = torch.tensor(list(mx.Ctx.unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(buf, 0)
+        uid = bytes(buf.cpu().tolist())
+    ctx = mx.Ctx(local, rank, world, uid)
+
+    shift = 0.05 * (2.0 * np.pi) ** 2          # src/mx.py:711-712 default for the unit box
+    t0 = time.perf_counter()
+    if world == 1:
+        sim = mx.Sim.pillbox(args.n)
+        A = sim.to_device(ctx, "vecLapl", shift=shift)
+        workload = "pillbox %d^3 Yee cells, vecLapl - shift*dmA (example/pillbox.py geometry)" % args.n
+        parallelism = "1 GPU"
+    else:
+        from maxwell_amd import distributed as mxd
+        sim, A, workload, parallelism = mxd.bench_setup(ctx, args.n, shift)
+    setup_s = time.perf_counter() - t0
+    log("rank %d setup %.1f s: rows %d nnz %d" % (rank, setup_s, A.nrows, A.nnz))
+    A.set_kernel(args.kernel)
+
+    X = mx.MultiVec(ctx, A.ncols, args.k)
+    Y = mx.MultiVec(ctx, A.nrows, args.k)
+    X.random(12345)
+    for _ in range(args.warmup):
+        A.apply(X, Y)
+    ctx.sync()
+    if dist: dist.barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        A.apply(X, Y)
+    ev_ms = ctx.timer_stop()                   # HIP events on the ctx stream (includes ctx.sync)
+    if dist: dist.barrier()
+    wall = time.perf_counter() - t0
+    alg = A.apply_bytes(args.k)
+    rows, nnz = A.nrows, A.nnz
+    if dist:
+        import torch
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = t.tolist()
+        s = torch.tensor([alg, rows, nnz], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        alg, rows, nnz = [int(v) for v in s.tolist()]
+    ms_per_step = wall * 1e3 / args.steps
+    value = alg * args.steps / wall / 1e9
+    kern_ms = ev_ms / args.steps
+    achieved = alg / world / (kern_ms * 1e-3) / 1e9   # per GPU, dominant kernel
+
+    out = {
+        "metric": "MxMagWaveOp SpMV achieved HBM GB/s (eigenpairs/s in `eigen`)",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "rows": rows, "nnz": nnz, "block_vectors": args.k,
+                   "parallelism": parallelism, "index_types": "int64 rowptr, int32 colidx",
+                   "setup_seconds": round(setup_s, 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "k_spmv_stream<false>" if args.kernel == 0 else "k_spmv_vector<8>",
+                     "kernel_ms": round(kern_ms, 5),
+                     "algorithmic_bytes_per_launch": alg // world,
+                     "note": "achieved = nnz*12 + rows*(8+8k) + cols*8k bytes / HIP-event time per launch"},
+    }
+    if rank == 0 and args.cpu_seconds > 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(sim, shift, A.nrows, alg, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if args.eig_n > 0 and world == 1:
+        try:
+            out["eigen"] = eigen_bench(mx, ctx, args.eig_n)
+        except Exception as e:   # the SpMV line must still print
+            out["eigen"] = {"error": str(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def eigen_bench(mx, ctx, n):
+    """eigenpairs/s = converged pairs / wall time of MxSolver::solve() (src/MxSolver.cpp:102-113)."""
+    sim = mx.Sim.pillbox(n)
+    params = mx.SolverParams(nev=5, basis=30, tol=1e-8, shift=0.05 * (2.0 * np.pi) ** 2,
+                             lin_type="cg", lin_tol=1e-9, prec_type="jacobi")
+    solver = mx.Solver(ctx, sim, params)
+    nconv = solver.solve()
+    st = solver.stats()
+    res = [solver.result(i) for i in range(nconv)]
+    return {"workload": "pillbox %d^3, nev 5, block Krylov-Schur shift-invert, CG inner solves" % n,
+            "eigenpairs_per_s": round(nconv / st["eigensolve_seconds"], 4), "converged": nconv,
+            "eigensolve_seconds": round(st["eigensolve_seconds"], 3), "applies": st["applies"],
+            "vec_lin_iters": st["vec_iters"], "sca_lin_iters": st["sca_iters"],
+            "k2": [round(r["k2"].real, 10) for r in res],
+            "max_rel_residual": max(r["residual"] for r in res) if res else None}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+/*
+ * mxh.h -- C ABI of the host-side library (libmxhost.so): problem setup (Yee / Dey-Mittra
+ * operator assembly, the MxMagWaveOp matrices) and the eigen-driver, written in C++ above the
+ * device ABI of mxg.h.  This is what a Python / ctypes front end (tests, bench.py, the
+ * example/*.py drivers) binds instead of shelling out to the `maxwell` binary
+ * (reference example/pillbox.py:44-50, src/maxwell.cpp:64-119, src/MxProblem.cpp:111-201).
+ *
+ * All functions return 0 on success; mxh_last_error() gives the message otherwise.
+ */
+#ifndef MXH_H
+#define MXH_H
+
+#include <stdint.h>
+
+#include "mxg.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mxh_sim mxh_sim;
+typedef struct mxh_solver mxh_solver;
+
+const char* mxh_last_error(void);
+
+/* Grid + boundary conditions + PEC shape  (MxGrid, MxEMSim::setup; src/MxEMSim.cpp:54-225).
+ *   lower/upper: 3 strings out of "periodic" | "pec" | "pmc"  (src/MxProblem.cpp:441-470)
+ *   pec_shape:   NULL/"" for none, else primitives joined by '&' (ShapeIntersection):
+ *                  cylinder(r; ax,ay,az; x,y,z)   slab(t; nx,ny,nz; x,y,z)
+ *                  sphere(r; x,y,z)               halfspace(nx,ny,nz; x,y,z)
+ *   strict:      1 = reference behaviour incl. the periodic-wrap quirk of
+ *                MxYeeFitEField::getCompFactor, 0 = wrap-corrected */
+int mxh_sim_create(const int n[3], const double origin[3], const double size[3],
+                   const char* const lower[3], const char* const upper[3], const char* pec_shape,
+                   int strict, mxh_sim** out);
+int mxh_sim_destroy(mxh_sim* s);
+
+/* Borrowed views (valid until mxh_sim_destroy) of a named operator in local CSR form:
+ * curlE curlB divB gradPsi dmA dmL dmVInv curlCurl gradDiv vecLapl scaLapl mRhs
+ * (MxEMOps::getOp, src/MxEMOps.cpp:171-183; MxMagWaveOp::initMatrices, src/MxMagWaveOp.cpp:138-245) */
+int mxh_sim_op(mxh_sim* s, const char* name, int64_t* nrows, int64_t* ncols, int64_t* nnz,
+               const int64_t** rowptr, const int32_t** colidx, const double** vals);
+/* vecLapl - shift * mRhs (MxMagWaveOp::setShift, src/MxMagWaveOp.cpp:248-255); cached per shift */
+int mxh_sim_shifted(mxh_sim* s, double shift, int64_t* nrows, int64_t* nnz, const int64_t** rowptr,
+                    const int32_t** colidx, const double** vals);
+/* global ids of a field map: "bfield" | "efield" | "psifield" (MxGridField::getMap) */
+int mxh_sim_map(mxh_sim* s, const char* field, int64_t* n, const int64_t** gids);
+/* 0/1 per B-map row: 0 where the component is unused (zero area fraction / zero BC factor);
+ * what MxGridField::zeroUnusedComponents clears (src/MxSolver.cpp:65) */
+int mxh_sim_used_mask(mxh_sim* s, int64_t* n, const double** mask);
+/* seconds spent in assembly (fractions + primitive operators + products) */
+double mxh_sim_setup_seconds(const mxh_sim* s);
+
+/* ---------------------------------------------------------------------------------------
+ * Eigen-driver: MxSolver + MxMagWaveOp on one GPU context
+ * (src/MxSolver.cpp:24-94 ctor, :100-239 solve; src/MxMagWaveOp.cpp:826-943 Apply)
+ * ------------------------------------------------------------------------------------- */
+typedef struct mxh_solver_params {
+  int nev;               /* "eigensolver : nev"            (default 10, src/MxProblem.cpp:31) */
+  int basis;             /* "eigensolver : basis"          (default 20) = Anasazi Num Blocks */
+  int block_size;        /* "eigensolver : block size"     (default 1) */
+  int max_restarts;      /* "eigensolver : max restarts"   (default 100) */
+  double tol;            /* "eigensolver : tol"            (default 1e-6) */
+  double shift;          /* "eigensolver : shift" */
+  const char* lin_type;  /* "linear solver : type": "gmres" | "cg"  (default gmres) */
+  int lin_basis;         /* "linear solver : basis"        (default 40) */
+  double lin_tol;        /* "linear solver : tol"          (default 1e-6) */
+  const char* prec_type; /* "linear solver : prec type": "none" | "jacobi" (ilu/amg map to jacobi) */
+  int verbose;
+  uint64_t seed;
+} mxh_solver_params;
+
+void mxh_solver_default_params(mxh_solver_params* p);
+int mxh_solver_create(mxg_ctx* ctx, mxh_sim* sim, const mxh_solver_params* p, mxh_solver** out);
+int mxh_solver_destroy(mxh_solver* s);
+/* runs MxSolver::solve(); returns the number of converged eigenpairs in *nconv */
+int mxh_solver_solve(mxh_solver* s, int* nconv);
+/* per converged pair i: Anasazi eigenvalue theta (re, im), k^2 = 1/theta + shift, frequency in Hz
+ * (eigValsToFreqs), relative residual (checkEigensolution) and divergence norm (checkDivergences) */
+int mxh_solver_result(mxh_solver* s, int i, double theta[2], double k2[2], double freq[2],
+                      double* residual, double* divergence);
+/* counters of src/MxMagWaveOp.cpp:97-115 plus the eigensolve wall time of src/MxSolver.cpp:102-113 */
+int mxh_solver_stats(mxh_solver* s, int* num_applies, int* vec_lin_iters, int* sca_lin_iters,
+                     double* vec_solve_seconds, double* sca_solve_seconds, double* eigensolve_seconds);
+/* copy eigenvector i of the B field (local rows) to host */
+int mxh_solver_eigvec(mxh_solver* s, int i, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXH_H */

@@ -1,0 +1,81 @@
+"""Build the native libraries in-tree (maxwell_amd/lib/*.so).
+
+  libmxg.so     HIP kernels + the C ABI of include/mxg.h       (hipcc --offload-arch=gfx950)
+  libmxhost.so  host C++: assembly, drop-in classes, eigen-driver, C ABI of include/mxh.h (g++)
+
+hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the CPU-only
+container; the built .so files travel to the GPU box with the repository snapshot.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "maxwell_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "maxwell_amd", "lib")
+INCLUDE = os.path.join(ROOT, "include")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+DEVICE_SOURCES = ["mxg_ctx.hip", "mxg_mv.hip", "mxg_csr.hip", "mxg_solve.hip"]
+HOST_SOURCES = ["mx_geometry.cpp", "mx_yee.cpp", "mxh_sim.cpp", "mxh_solver.cpp"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _deps(directory, extra=()):
+    out = [os.path.join(directory, f) for f in os.listdir(directory)]
+    out += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    mxdir = os.path.join(INCLUDE, "mx")
+    if os.path.isdir(mxdir):
+        out += [os.path.join(mxdir, f) for f in os.listdir(mxdir)]
+    return out + list(extra)
+
+
+def _run(cmd, cwd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, cwd=cwd, check=True)
+
+
+def build_device(force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    src_dir = os.path.join(CSRC, "device")
+    target = os.path.join(LIBDIR, "libmxg.so")
+    if not force and not _newer(target, _deps(src_dir)):
+        return target
+    hipcc = os.path.join(ROCM, "bin", "hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-value", "-Wno-unused-result", "-ffp-contract=off",
+           "-I" + INCLUDE, "-I" + src_dir] + DEVICE_SOURCES + \
+          ["-o", target, "-L" + os.path.join(ROCM, "lib"), "-lrccl",
+           "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    _run(cmd, src_dir)
+    return target
+
+
+def build_host(force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    src_dir = os.path.join(CSRC, "host")
+    target = os.path.join(LIBDIR, "libmxhost.so")
+    libmxg = os.path.join(LIBDIR, "libmxg.so")
+    if not force and not _newer(target, _deps(src_dir, [libmxg])):
+        return target
+    # -ffp-contract=off: assembled matrix values must not depend on FMA contraction
+    cmd = ["g++", "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-I" + INCLUDE, "-I" + src_dir] + HOST_SOURCES + \
+          ["-o", target, "-L" + LIBDIR, "-lmxg", "-Wl,-rpath,$ORIGIN"]
+    _run(cmd, src_dir)
+    return target
+
+
+def build_all(force=False):
+    build_device(force)
+    build_host(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,132 @@
+"""ctypes bindings of include/mxg.h and include/mxh.h (loud failure if a library is missing)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_HERE, "lib")
+
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+class MxError(RuntimeError):
+    pass
+
+
+class HaloPlan(C.Structure):
+    _fields_ = [("nneigh", C.c_int), ("neigh", c_ip), ("send_off", c_i64p),
+                ("send_idx", c_i64p), ("recv_off", c_i64p)]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("restart", C.c_int), ("max_iters", C.c_int),
+                ("precond", C.c_int), ("cheb_degree", C.c_int),
+                ("lmin", C.c_double), ("lmax", C.c_double)]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iters", C.c_int), ("converged", C.c_int), ("true_res", C.c_double)]
+
+
+class SolverParamsC(C.Structure):
+    _fields_ = [("nev", C.c_int), ("basis", C.c_int), ("block_size", C.c_int),
+                ("max_restarts", C.c_int), ("tol", C.c_double), ("shift", C.c_double),
+                ("lin_type", C.c_char_p), ("lin_basis", C.c_int), ("lin_tol", C.c_double),
+                ("prec_type", C.c_char_p), ("verbose", C.c_int), ("seed", C.c_uint64)]
+
+
+# name -> (restype, argtypes); the list doubles as the export check of the CPU test-suite
+MXG_SIGNATURES = {
+    "mxg_last_error": (C.c_char_p, []),
+    "mxg_get_unique_id": (C.c_int, [vp]),
+    "mxg_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "mxg_ctx_destroy": (C.c_int, [vp]),
+    "mxg_ctx_sync": (C.c_int, [vp]),
+    "mxg_ctx_rank": (C.c_int, [vp]),
+    "mxg_ctx_nranks": (C.c_int, [vp]),
+    "mxg_timer_start": (C.c_int, [vp]),
+    "mxg_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "mxg_barrier": (C.c_int, [vp]),
+    "mxg_csr_create": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, C.c_int,
+                                 C.POINTER(HaloPlan), C.POINTER(vp)]),
+    "mxg_csr_destroy": (C.c_int, [vp]),
+    "mxg_csr_info": (C.c_int, [vp, c_i64p, c_i64p, c_i64p, c_i64p, c_ip]),
+    "mxg_csr_apply": (C.c_int, [vp, vp, vp, vp]),
+    "mxg_csr_apply_bytes": (C.c_int64, [vp, C.c_int]),
+    "mxg_csr_set_kernel": (C.c_int, [vp, C.c_int]),
+    "mxg_mv_create": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.POINTER(vp)]),
+    "mxg_mv_view": (C.c_int, [vp, c_ip, C.c_int, C.POINTER(vp)]),
+    "mxg_mv_clone": (C.c_int, [vp, c_ip, C.c_int, C.POINTER(vp)]),
+    "mxg_mv_destroy": (C.c_int, [vp]),
+    "mxg_mv_info": (C.c_int, [vp, c_i64p, c_ip, c_ip]),
+    "mxg_mv_put": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int64, vp]),
+    "mxg_mv_fetch": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int64, vp]),
+    "mxg_mv_copy": (C.c_int, [vp, vp]),
+    "mxg_mv_fill": (C.c_int, [vp, C.c_double, C.c_double]),
+    "mxg_mv_random": (C.c_int, [vp, C.c_uint64]),
+    "mxg_mv_conj": (C.c_int, [vp]),
+    "mxg_mv_scale": (C.c_int, [vp, C.c_double, C.c_double]),
+    "mxg_mv_scale_cols": (C.c_int, [vp, vp]),
+    "mxg_mv_mask_rows": (C.c_int, [vp, vp]),
+    "mxg_mv_axpby": (C.c_int, [C.c_double, C.c_double, vp, C.c_double, C.c_double, vp]),
+    "mxg_mv_add": (C.c_int, [C.c_double, C.c_double, vp, C.c_double, C.c_double, vp, vp]),
+    "mxg_mv_dot": (C.c_int, [vp, vp, vp]),
+    "mxg_mv_norm2": (C.c_int, [vp, vp]),
+    "mxg_mv_set_block": (C.c_int, [vp, vp, c_ip, C.c_int]),
+    "mxg_mv_times_mat": (C.c_int, [C.c_double, C.c_double, vp, vp, C.c_int, C.c_int, C.c_int,
+                                   C.c_double, C.c_double, vp]),
+    "mxg_mv_trans_mv": (C.c_int, [C.c_double, C.c_double, vp, vp, vp, C.c_int]),
+    "mxg_solve_cg": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
+    "mxg_solve_gmres": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
+}
+
+MXH_SIGNATURES = {
+    "mxh_last_error": (C.c_char_p, []),
+    "mxh_sim_create": (C.c_int, [C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_char_p),
+                                 C.POINTER(C.c_char_p), C.c_char_p, C.c_int, C.POINTER(vp)]),
+    "mxh_sim_destroy": (C.c_int, [vp]),
+    "mxh_sim_op": (C.c_int, [vp, C.c_char_p, c_i64p, c_i64p, c_i64p, C.POINTER(c_i64p),
+                             C.POINTER(c_i32p), C.POINTER(c_dp)]),
+    "mxh_sim_shifted": (C.c_int, [vp, C.c_double, c_i64p, c_i64p, C.POINTER(c_i64p),
+                                  C.POINTER(c_i32p), C.POINTER(c_dp)]),
+    "mxh_sim_map": (C.c_int, [vp, C.c_char_p, c_i64p, C.POINTER(c_i64p)]),
+    "mxh_sim_used_mask": (C.c_int, [vp, c_i64p, C.POINTER(c_dp)]),
+    "mxh_sim_setup_seconds": (C.c_double, [vp]),
+    "mxh_solver_default_params": (None, [C.POINTER(SolverParamsC)]),
+    "mxh_solver_create": (C.c_int, [vp, vp, C.POINTER(SolverParamsC), C.POINTER(vp)]),
+    "mxh_solver_destroy": (C.c_int, [vp]),
+    "mxh_solver_solve": (C.c_int, [vp, c_ip]),
+    "mxh_solver_result": (C.c_int, [vp, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "mxh_solver_stats": (C.c_int, [vp, c_ip, c_ip, c_ip, c_dp, c_dp, c_dp]),
+    "mxh_solver_eigvec": (C.c_int, [vp, C.c_int, vp]),
+}
+
+_cache = {}
+
+
+def _load(name, signatures):
+    if name in _cache:
+        return _cache[name]
+    path = os.path.join(_LIBDIR, name)
+    if not os.path.exists(path):
+        raise MxError("%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback for the hot path)" % path)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for fn, (res, args) in signatures.items():
+        f = getattr(lib, fn)   # AttributeError here = the library misses a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _cache[name] = lib
+    return lib
+
+
+def load_mxg():
+    return _load("libmxg.so", MXG_SIGNATURES)
+
+
+def load_mxhost():
+    load_mxg()
+    return _load("libmxhost.so", MXH_SIGNATURES)

@@ -1,0 +1,412 @@
+"""Python mirror of the reference's host interface for the hot path, over the C ABI.
+
+Names follow the reference: CsrMatrix.apply = MxCrsMatrix::apply, MultiVec methods =
+MxMultiVector / MxAnasaziMV methods (src/MxMultiVector.hpp:14-109, src/MxAnasaziMV.hpp:23-132),
+Sim = MxEMSim + MxEMOps, Solver = MxSolver.  Every call goes to the HIP library; numpy is only
+used to move data in and out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MxError
+
+
+def _chk(rc, lib, which="mxg"):
+    if rc != 0:
+        msg = (lib.mxg_last_error() if which == "mxg" else lib.mxh_last_error()) or b""
+        raise MxError(msg.decode(errors="replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Ctx:
+    """One GPU / rank (replaces MxComm, src/MxComm.hpp:14-37)."""
+
+    def __init__(self, device=0, rank=0, nranks=1, unique_id=None):
+        self.lib = _lib.load_mxg()
+        h = C.c_void_p()
+        uid = None
+        if unique_id is not None:
+            self._uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+            uid = C.cast(self._uid, C.c_void_p)
+        _chk(self.lib.mxg_ctx_create(device, rank, nranks, uid, C.byref(h)), self.lib)
+        self.h = h
+        self.rank, self.nranks = rank, nranks
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load_mxg()
+        buf = (C.c_char * 128)()
+        _chk(lib.mxg_get_unique_id(C.cast(buf, C.c_void_p)), lib)
+        return bytes(buf)
+
+    def sync(self):
+        _chk(self.lib.mxg_ctx_sync(self.h), self.lib)
+
+    def barrier(self):
+        _chk(self.lib.mxg_barrier(self.h), self.lib)
+
+    def timer_start(self):
+        _chk(self.lib.mxg_timer_start(self.h), self.lib)
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _chk(self.lib.mxg_timer_stop(self.h, C.byref(ms)), self.lib)
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.mxg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiVec:
+    """MxMultiVector / MxAnasaziMV on the device (column-major, complex interleaved)."""
+
+    def __init__(self, ctx, nlocal=None, k=1, is_complex=False, _handle=None, _parent=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self._parent = _parent   # keep the owner alive while a view exists
+        if _handle is None:
+            h = C.c_void_p()
+            _chk(self.lib.mxg_mv_create(ctx.h, int(nlocal), int(k), int(bool(is_complex)), C.byref(h)),
+                 self.lib)
+            _handle = h
+        self.h = _handle
+        n, kk, cx = C.c_int64(), C.c_int(), C.c_int()
+        self.lib.mxg_mv_info(self.h, C.byref(n), C.byref(kk), C.byref(cx))
+        self.nlocal, self.k, self.is_complex = n.value, kk.value, bool(cx.value)
+
+    # -- construction helpers
+    @classmethod
+    def from_numpy(cls, ctx, a):
+        a = np.asarray(a)
+        if a.ndim == 1:
+            a = a[:, None]
+        cx = np.iscomplexobj(a)
+        mv = cls(ctx, a.shape[0], a.shape[1], cx)
+        mv.set(a)
+        return mv
+
+    def set(self, a):
+        a = np.asarray(a)
+        if a.ndim == 1:
+            a = a[:, None]
+        dt = np.complex128 if self.is_complex else np.float64
+        for j in range(self.k):
+            col = np.ascontiguousarray(a[:, j], dtype=dt)
+            _chk(self.lib.mxg_mv_put(self.h, j, 0, self.nlocal, _ptr(col)), self.lib)
+
+    def to_numpy(self):
+        dt = np.complex128 if self.is_complex else np.float64
+        out = np.empty((self.nlocal, self.k), dtype=dt, order="F")
+        for j in range(self.k):
+            col = np.empty(self.nlocal, dtype=dt)
+            _chk(self.lib.mxg_mv_fetch(self.h, j, 0, self.nlocal, _ptr(col)), self.lib)
+            out[:, j] = col
+        return out
+
+    def view(self, cols):        # CloneView / CloneViewNonConst
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        h = C.c_void_p()
+        _chk(self.lib.mxg_mv_view(self.h, cols.ctypes.data_as(C.POINTER(C.c_int)), len(cols), C.byref(h)),
+             self.lib)
+        return MultiVec(self.ctx, _handle=h, _parent=self)
+
+    def clone(self, cols=None):  # CloneCopy
+        h = C.c_void_p()
+        if cols is None:
+            _chk(self.lib.mxg_mv_clone(self.h, None, 0, C.byref(h)), self.lib)
+        else:
+            cols = np.ascontiguousarray(cols, dtype=np.int32)
+            _chk(self.lib.mxg_mv_clone(self.h, cols.ctypes.data_as(C.POINTER(C.c_int)), len(cols),
+                                       C.byref(h)), self.lib)
+        return MultiVec(self.ctx, _handle=h)
+
+    # -- MxMultiVector interface
+    def copy_from(self, other):
+        _chk(self.lib.mxg_mv_copy(self.h, other.h), self.lib)
+
+    def fill(self, val):         # set / MvInit
+        val = complex(val)
+        _chk(self.lib.mxg_mv_fill(self.h, val.real, val.imag), self.lib)
+
+    def random(self, seed=0):
+        _chk(self.lib.mxg_mv_random(self.h, int(seed)), self.lib)
+
+    def conj(self):
+        _chk(self.lib.mxg_mv_conj(self.h), self.lib)
+
+    def scale(self, a):
+        if np.ndim(a) == 0:
+            a = complex(a)
+            _chk(self.lib.mxg_mv_scale(self.h, a.real, a.imag), self.lib)
+        else:
+            dt = np.complex128 if self.is_complex else np.float64
+            al = np.ascontiguousarray(a, dtype=dt)
+            assert al.shape == (self.k,)
+            _chk(self.lib.mxg_mv_scale_cols(self.h, _ptr(al)), self.lib)
+
+    def mask_rows(self, mask):
+        _chk(self.lib.mxg_mv_mask_rows(self.h, mask.h), self.lib)
+
+    def update(self, a, A, b):   # this = a*A + b*this
+        a, b = complex(a), complex(b)
+        _chk(self.lib.mxg_mv_axpby(a.real, a.imag, A.h, b.real, b.imag, self.h), self.lib)
+
+    def add_mv(self, a, A, b, B):   # MvAddMv: this = a*A + b*B
+        a, b = complex(a), complex(b)
+        _chk(self.lib.mxg_mv_add(a.real, a.imag, A.h, b.real, b.imag, B.h, self.h), self.lib)
+
+    def dot(self, A):            # res[j] = A_j^H this_j  (MvDot / dot(mv, res))
+        w = 2 if self.is_complex else 1
+        res = np.empty(self.k * w)
+        _chk(self.lib.mxg_mv_dot(A.h, self.h, _ptr(res)), self.lib)
+        return res.view(np.complex128) if self.is_complex else res
+
+    def norm2(self):
+        res = np.empty(self.k)
+        _chk(self.lib.mxg_mv_norm2(self.h, _ptr(res)), self.lib)
+        return res
+
+    def set_block(self, A, index):
+        index = np.ascontiguousarray(index, dtype=np.int32)
+        _chk(self.lib.mxg_mv_set_block(self.h, A.h, index.ctypes.data_as(C.POINTER(C.c_int)), len(index)),
+             self.lib)
+
+    def times_mat_add_mv(self, alpha, A, B, beta):   # this = alpha*A*B + beta*this
+        dt = np.complex128 if self.is_complex else np.float64
+        B = np.asfortranarray(B, dtype=dt)
+        m, k = B.shape
+        alpha, beta = complex(alpha), complex(beta)
+        _chk(self.lib.mxg_mv_times_mat(alpha.real, alpha.imag, A.h, _ptr(B), m, m, k,
+                                       beta.real, beta.imag, self.h), self.lib)
+
+    def trans_mv(self, alpha, A):   # B = alpha * A^H * this
+        dt = np.complex128 if self.is_complex else np.float64
+        B = np.empty((A.k, self.k), dtype=dt, order="F")
+        alpha = complex(alpha)
+        _chk(self.lib.mxg_mv_trans_mv(alpha.real, alpha.imag, A.h, self.h, _ptr(B), A.k), self.lib)
+        return B
+
+    def close(self):
+        if self.h:
+            self.lib.mxg_mv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CsrMatrix:
+    """MxCrsMatrix on the device; apply() = SpMV / SpMM."""
+
+    def __init__(self, ctx, nrows, ncols, rowptr, colidx, vals, is_complex=False, nghost=0, plan=None,
+                 _keep=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        h = C.c_void_p()
+        _chk(self.lib.mxg_csr_create(ctx.h, int(nrows), int(ncols), int(nghost), rowptr, colidx, vals,
+                                     int(bool(is_complex)), plan, C.byref(h)), self.lib)
+        self.h = h
+        self.nrows, self.ncols, self.is_complex = int(nrows), int(ncols), bool(is_complex)
+        n = C.c_int64()
+        self.lib.mxg_csr_info(self.h, None, None, None, C.byref(n), None)
+        self.nnz = n.value
+
+    @classmethod
+    def from_scipy(cls, ctx, m, nghost=0, plan=None):
+        m = m.tocsr()
+        cx = np.iscomplexobj(m.data)
+        rowptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+        col = np.ascontiguousarray(m.indices, dtype=np.int32)
+        val = np.ascontiguousarray(m.data, dtype=np.complex128 if cx else np.float64)
+        return cls(ctx, m.shape[0], m.shape[1] - nghost, _ptr(rowptr), _ptr(col), _ptr(val), cx,
+                   nghost=nghost, plan=plan)
+
+    def apply(self, x, y):
+        _chk(self.lib.mxg_csr_apply(self.ctx.h, self.h, x.h, y.h), self.lib)
+
+    def apply_bytes(self, k=1):
+        return self.lib.mxg_csr_apply_bytes(self.h, k)
+
+    def set_kernel(self, which):
+        self.lib.mxg_csr_set_kernel(self.h, which)
+
+    def solve(self, b, x, method="cg", tol=1e-6, restart=40, max_iters=0, precond="none"):
+        opts = _lib.SolveOpts(tol, restart, max_iters, {"none": 0, "jacobi": 1}[precond], 0, 0.0, 0.0)
+        info = _lib.SolveInfo()
+        fn = self.lib.mxg_solve_cg if method == "cg" else self.lib.mxg_solve_gmres
+        _chk(fn(self.ctx.h, self.h, b.h, x.h, C.byref(opts), C.byref(info)), self.lib)
+        return info.iters, bool(info.converged), info.true_res
+
+    def close(self):
+        if self.h:
+            self.lib.mxg_csr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+PILLBOX_SHAPE = "cylinder(0.4;0,0,1;0,0,0)&slab(0.8;0,0,1;0,0,0)"
+
+
+class Sim:
+    """Grid + BCs + PEC shape -> assembled operators (MxEMSim::setup + MxEMOps + initMatrices)."""
+
+    def __init__(self, n, origin=(0.0, 0.0, 0.0), size=(1.0, 1.0, 1.0), lower=("periodic",) * 3,
+                 upper=("periodic",) * 3, pec_shape=None, strict=True):
+        self.lib = _lib.load_mxhost()
+        n = [int(n)] * 3 if np.ndim(n) == 0 else [int(v) for v in n]
+        self.n = n
+        nn = (C.c_int * 3)(*n)
+        oo = (C.c_double * 3)(*origin)
+        ss = (C.c_double * 3)(*size)
+        lo = (C.c_char_p * 3)(*[s.encode() for s in lower])
+        up = (C.c_char_p * 3)(*[s.encode() for s in upper])
+        h = C.c_void_p()
+        _chk(self.lib.mxh_sim_create(nn, oo, ss, lo, up, pec_shape.encode() if pec_shape else None,
+                                     int(bool(strict)), C.byref(h)), self.lib, "mxh")
+        self.h = h
+
+    @classmethod
+    def pillbox(cls, n, **kw):
+        """example/pillbox.py geometry at resolution n."""
+        return cls(n, origin=(-0.5,) * 3, size=(1.0,) * 3, pec_shape=PILLBOX_SHAPE, **kw)
+
+    def op_raw(self, name, shift=None):
+        """(nrows, ncols, nnz, rowptr*, colidx*, vals*) borrowed from the C++ side (no copies)."""
+        nr, nc, nz = C.c_int64(), C.c_int64(), C.c_int64()
+        rp, ci, va = _lib.c_i64p(), _lib.c_i32p(), _lib.c_dp()
+        if shift is None:
+            _chk(self.lib.mxh_sim_op(self.h, name.encode(), C.byref(nr), C.byref(nc), C.byref(nz),
+                                     C.byref(rp), C.byref(ci), C.byref(va)), self.lib, "mxh")
+        else:
+            _chk(self.lib.mxh_sim_shifted(self.h, float(shift), C.byref(nr), C.byref(nz), C.byref(rp),
+                                          C.byref(ci), C.byref(va)), self.lib, "mxh")
+            nc = nr
+        return nr.value, nc.value, nz.value, rp, ci, va
+
+    def op(self, name, shift=None):
+        """scipy.sparse copy of a named operator (tests)."""
+        import scipy.sparse as sp
+        nr, nc, nz, rp, ci, va = self.op_raw(name, shift)
+        rowptr = np.ctypeslib.as_array(rp, (nr + 1,)).copy()
+        col = np.ctypeslib.as_array(ci, (max(nz, 1),))[:nz].copy()
+        val = np.ctypeslib.as_array(va, (max(nz, 1),))[:nz].copy()
+        return sp.csr_matrix((val, col, rowptr), shape=(nr, nc))
+
+    def to_device(self, ctx, name, shift=None):
+        nr, nc, nz, rp, ci, va = self.op_raw(name, shift)
+        return CsrMatrix(ctx, nr, nc, C.cast(rp, C.c_void_p), C.cast(ci, C.c_void_p),
+                         C.cast(va, C.c_void_p), False)
+
+    def map(self, field):
+        n, g = C.c_int64(), _lib.c_i64p()
+        _chk(self.lib.mxh_sim_map(self.h, field.encode(), C.byref(n), C.byref(g)), self.lib, "mxh")
+        return np.ctypeslib.as_array(g, (max(n.value, 1),))[:n.value].copy()
+
+    def used_mask(self):
+        n, m = C.c_int64(), _lib.c_dp()
+        _chk(self.lib.mxh_sim_used_mask(self.h, C.byref(n), C.byref(m)), self.lib, "mxh")
+        return np.ctypeslib.as_array(m, (max(n.value, 1),))[:n.value].copy()
+
+    @property
+    def setup_seconds(self):
+        return self.lib.mxh_sim_setup_seconds(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.mxh_sim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SolverParams:
+    """The `eigensolver : *` / `linear solver : *` parameters MxSolver reads
+    (src/MxSolver.cpp:27-38, src/MxProblem.cpp:26-67)."""
+
+    def __init__(self, **kw):
+        lib = _lib.load_mxhost()
+        self.c = _lib.SolverParamsC()
+        lib.mxh_solver_default_params(C.byref(self.c))
+        self._keep = []
+        for k, v in kw.items():
+            self.set(k, v)
+
+    def set(self, k, v):
+        if k in ("lin_type", "prec_type"):
+            b = v.encode()
+            self._keep.append(b)
+            setattr(self.c, k, b)
+        else:
+            setattr(self.c, k, v)
+
+
+class Solver:
+    """MxSolver: block Krylov-Schur in shift-invert mode around MxMagWaveOp::Apply."""
+
+    def __init__(self, ctx, sim, params=None):
+        self.lib = _lib.load_mxhost()
+        self.ctx, self.sim = ctx, sim
+        self.params = params or SolverParams()
+        h = C.c_void_p()
+        _chk(self.lib.mxh_solver_create(ctx.h, sim.h, C.byref(self.params.c), C.byref(h)), self.lib, "mxh")
+        self.h = h
+
+    def solve(self):
+        n = C.c_int()
+        _chk(self.lib.mxh_solver_solve(self.h, C.byref(n)), self.lib, "mxh")
+        self.nconv = n.value
+        return self.nconv
+
+    def result(self, i):
+        th, k2, fr = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_double * 2)()
+        res, dv = C.c_double(), C.c_double()
+        _chk(self.lib.mxh_solver_result(self.h, i, th, k2, fr, C.byref(res), C.byref(dv)), self.lib, "mxh")
+        return dict(theta=complex(th[0], th[1]), k2=complex(k2[0], k2[1]), freq=complex(fr[0], fr[1]),
+                    residual=res.value, divergence=dv.value)
+
+    def stats(self):
+        a, v, s = C.c_int(), C.c_int(), C.c_int()
+        tv, ts, te = C.c_double(), C.c_double(), C.c_double()
+        _chk(self.lib.mxh_solver_stats(self.h, C.byref(a), C.byref(v), C.byref(s), C.byref(tv),
+                                       C.byref(ts), C.byref(te)), self.lib, "mxh")
+        return dict(applies=a.value, vec_iters=v.value, sca_iters=s.value, vec_seconds=tv.value,
+                    sca_seconds=ts.value, eigensolve_seconds=te.value)
+
+    def eigvec(self, i, n):
+        out = np.empty(n)
+        _chk(self.lib.mxh_solver_eigvec(self.h, i, _ptr(out)), self.lib, "mxh")
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.mxh_solver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

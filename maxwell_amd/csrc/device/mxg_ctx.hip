@@ -1,0 +1,154 @@
+// Context: device, stream, RCCL communicator, workspaces, timers.
+// Replaces MxComm / Epetra_MpiComm (reference src/MxComm.hpp:14-37): one process per GPU,
+// collectives go through RCCL on the ctx stream.
+#include <cstdarg>
+
+#include "mxg_internal.h"
+
+static thread_local std::string g_last_error;
+
+void mxg_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+extern "C" const char* mxg_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int mxg_get_unique_id(void* out_id) {
+  static_assert(sizeof(ncclUniqueId) <= MXG_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  MXG_NCCL(ncclGetUniqueId(&id));
+  memset(out_id, 0, MXG_UNIQUE_ID_BYTES);
+  memcpy(out_id, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int mxg_ctx_create(int device, int rank, int nranks, const void* nccl_unique_id,
+                              mxg_ctx** out) {
+  MXG_CHECK(out != nullptr, "mxg_ctx_create: out is NULL");
+  int ndev = 0;
+  MXG_HIP(hipGetDeviceCount(&ndev));
+  MXG_CHECK(ndev > 0, "mxg_ctx_create: no HIP device visible");
+  MXG_CHECK(device >= 0 && device < ndev, "mxg_ctx_create: device %d out of range (%d visible)",
+            device, ndev);
+  MXG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "mxg_ctx_create: bad rank %d / %d", rank,
+            nranks);
+  MXG_HIP(hipSetDevice(device));
+  mxg_ctx* c = new mxg_ctx();
+  c->device = device;
+  c->rank = rank;
+  c->nranks = nranks;
+  hipDeviceProp_t prop;
+  MXG_HIP(hipGetDeviceProperties(&prop, device));
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  MXG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  MXG_HIP(hipEventCreate(&c->ev0));
+  MXG_HIP(hipEventCreate(&c->ev1));
+  if (nranks > 1) {
+    MXG_CHECK(nccl_unique_id != nullptr, "mxg_ctx_create: nranks > 1 needs an RCCL unique id");
+    ncclUniqueId id;
+    memcpy(&id, nccl_unique_id, sizeof(id));
+    MXG_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+  }
+  if (mxg_ctx_reserve_reduce(c, 64) != 0) return 1;
+  *out = c;
+  return 0;
+}
+
+extern "C" int mxg_ctx_destroy(mxg_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  if (c->d_partial) hipFree(c->d_partial);
+  if (c->d_result) hipFree(c->d_result);
+  if (c->h_result) hipHostFree(c->h_result);
+  if (c->d_small) hipFree(c->d_small);
+  if (c->d_scratch) hipFree(c->d_scratch);
+  hipEventDestroy(c->ev0);
+  hipEventDestroy(c->ev1);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int mxg_ctx_sync(mxg_ctx* c) {
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int mxg_ctx_rank(const mxg_ctx* c) { return c->rank; }
+extern "C" int mxg_ctx_nranks(const mxg_ctx* c) { return c->nranks; }
+
+extern "C" int mxg_timer_start(mxg_ctx* c) {
+  MXG_HIP(hipEventRecord(c->ev0, c->stream));
+  return 0;
+}
+
+extern "C" int mxg_timer_stop(mxg_ctx* c, float* ms) {
+  MXG_HIP(hipEventRecord(c->ev1, c->stream));
+  MXG_HIP(hipEventSynchronize(c->ev1));
+  MXG_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+extern "C" int mxg_barrier(mxg_ctx* c) {
+  if (c->comm) {
+    MXG_HIP(hipMemsetAsync(c->d_result, 0, sizeof(double), c->stream));
+    MXG_NCCL(ncclAllReduce(c->d_result, c->d_result, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  }
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mxg_ctx_reserve_reduce(mxg_ctx* c, size_t width) {
+  if (width <= c->red_width) return 0;
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_partial) hipFree(c->d_partial);
+  if (c->d_result) hipFree(c->d_result);
+  if (c->h_result) hipHostFree(c->h_result);
+  size_t w = 64;
+  while (w < width) w *= 2;
+  MXG_HIP(hipMalloc(&c->d_partial, sizeof(double) * w * MXG_MAX_RED_BLOCKS));
+  MXG_HIP(hipMalloc(&c->d_result, sizeof(double) * w));
+  MXG_HIP(hipHostMalloc(&c->h_result, sizeof(double) * w, hipHostMallocDefault));
+  c->red_width = w;
+  return 0;
+}
+
+int mxg_ctx_reserve_small(mxg_ctx* c, size_t doubles) {
+  if (doubles <= c->small_cap) return 0;
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_small) hipFree(c->d_small);
+  size_t w = 4096;
+  while (w < doubles) w *= 2;
+  MXG_HIP(hipMalloc(&c->d_small, sizeof(double) * w));
+  c->small_cap = w;
+  return 0;
+}
+
+int mxg_ctx_reserve_scratch(mxg_ctx* c, size_t doubles) {
+  if (doubles <= c->scratch_cap) return 0;
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_scratch) hipFree(c->d_scratch);
+  MXG_HIP(hipMalloc(&c->d_scratch, sizeof(double) * doubles));
+  c->scratch_cap = doubles;
+  return 0;
+}
+
+int mxg_ctx_finish_reduce(mxg_ctx* c, size_t width, double* host_out) {
+  if (c->comm) {
+    // C2: the MPI_Allreduce inside Epetra_MultiVector::Dot / Norm2 / Multiply('T', ...)
+    MXG_NCCL(ncclAllReduce(c->d_result, c->d_result, width, ncclDouble, ncclSum, c->comm,
+                           c->stream));
+  }
+  MXG_HIP(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * width, hipMemcpyDeviceToHost,
+                         c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  memcpy(host_out, c->h_result, sizeof(double) * width);
+  return 0;
+}

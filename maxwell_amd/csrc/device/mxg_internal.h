@@ -1,0 +1,155 @@
+// Internal declarations shared by the translation units of libmxg.so.
+#ifndef MXG_INTERNAL_H
+#define MXG_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mxg.h"
+
+void mxg_set_error(const char* fmt, ...);
+
+#define MXG_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      mxg_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,                 \
+                    hipGetErrorString(e_));                                            \
+      return 1;                                                                        \
+    }                                                                                  \
+  } while (0)
+
+#define MXG_NCCL(call)                                                                 \
+  do {                                                                                 \
+    ncclResult_t e_ = (call);                                                          \
+    if (e_ != ncclSuccess) {                                                           \
+      mxg_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,                 \
+                    ncclGetErrorString(e_));                                           \
+      return 1;                                                                        \
+    }                                                                                  \
+  } while (0)
+
+#define MXG_CHECK(cond, ...)                                                           \
+  do {                                                                                 \
+    if (!(cond)) {                                                                     \
+      mxg_set_error(__VA_ARGS__);                                                      \
+      return 1;                                                                        \
+    }                                                                                  \
+  } while (0)
+
+#define MXG_TRY(call)                                                                  \
+  do {                                                                                 \
+    int rc_ = (call);                                                                  \
+    if (rc_ != 0) return rc_;                                                          \
+  } while (0)
+
+constexpr int MXG_NUM_XCD = 8;          // MI355X: 8 XCDs, workgroups dealt round-robin
+constexpr int MXG_MAX_RED_BLOCKS = 2048; // partial-sum slots of the two-stage reductions
+
+struct mxg_ctx {
+  int device = 0;
+  int rank = 0;
+  int nranks = 1;
+  hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // reduction workspace: partial sums + results (device), results (pinned host)
+  double* d_partial = nullptr;   // MXG_MAX_RED_BLOCKS * red_width doubles
+  double* d_result = nullptr;    // red_width doubles
+  double* h_result = nullptr;    // pinned, red_width doubles
+  size_t red_width = 0;          // capacity (number of simultaneous scalar results)
+  // small dense operand staging (B of K6) and int index staging
+  double* d_small = nullptr;
+  size_t small_cap = 0;          // doubles
+  // scratch vector storage for aliasing-safe applies (grown on demand)
+  double* d_scratch = nullptr;
+  size_t scratch_cap = 0;        // doubles
+  int num_cu = 256;
+};
+
+// View descriptor passed by value to kernels.
+struct MvDesc {
+  double* base;        // storage of column 0 of the owning allocation
+  long long ld;        // leading dimension in doubles (already x2 for complex)
+  long long n;         // local scalar rows
+  int k;               // columns in this view
+  int cplx;            // 0 real, 1 complex (interleaved)
+  int col0;            // first column when cols == nullptr (contiguous range)
+  const int* cols;     // device array of k column indices, or nullptr
+  __host__ __device__ inline double* col(int j) const {
+    long long c = cols ? (long long)cols[j] : (long long)(col0 + j);
+    return base + c * ld;
+  }
+};
+
+struct mxg_mv {
+  mxg_ctx* ctx = nullptr;
+  double* base = nullptr;     // allocation (owner) or parent's allocation (view)
+  int64_t nlocal = 0;         // scalar rows
+  int64_t ld = 0;             // doubles between columns
+  int ktotal = 0;             // columns in the allocation
+  int k = 0;                  // columns in this object
+  int is_complex = 0;
+  bool owner = false;
+  bool contiguous = true;
+  int col0 = 0;
+  std::vector<int> hcols;     // host copy of the column list (always filled, size k)
+  int* dcols = nullptr;       // device copy when !contiguous
+  MvDesc desc() const {
+    MvDesc d;
+    d.base = base; d.ld = ld; d.n = nlocal; d.k = k; d.cplx = is_complex;
+    d.col0 = col0; d.cols = contiguous ? nullptr : dcols;
+    return d;
+  }
+  double* colptr(int j) const { return base + (int64_t)hcols[j] * ld; }
+};
+
+struct mxg_csr {
+  mxg_ctx* ctx = nullptr;
+  int64_t nrows = 0, ncols_owned = 0, nghost = 0, nnz = 0;
+  int is_complex = 0;
+  int64_t* d_rowptr = nullptr;
+  int32_t* d_colidx = nullptr;
+  double* d_vals = nullptr;
+  // row blocks of the stream kernel: block b covers rows [rowblk[b], rowblk[b+1])
+  int32_t* d_rowblk = nullptr;
+  int64_t nblocks = 0;
+  int kernel = 0;
+  // diagonal (for Jacobi) extracted at creation
+  double* d_diag = nullptr;
+  // halo
+  int nneigh = 0;
+  std::vector<int> neigh;
+  std::vector<int64_t> send_off, recv_off;
+  int64_t* d_send_idx = nullptr;
+  int64_t nsend = 0;
+  double* d_sendbuf = nullptr;   // nsend * kcap scalars
+  double* d_xext = nullptr;      // (ncols_owned + nghost) * kcap scalars: x with ghosts appended
+  int halo_kcap = 0;
+};
+
+// reductions / workspace helpers (mxg_ctx.hip)
+int mxg_ctx_reserve_reduce(mxg_ctx* ctx, size_t width);
+int mxg_ctx_reserve_small(mxg_ctx* ctx, size_t doubles);
+int mxg_ctx_reserve_scratch(mxg_ctx* ctx, size_t doubles);
+// sum `width` device results across ranks (no-op for 1 rank), copy to host, sync
+int mxg_ctx_finish_reduce(mxg_ctx* ctx, size_t width, double* host_out);
+
+// device-side entry points used across translation units (results stay on device)
+// d_out[j] = sum_i conj(A_j[i]) * B_j[i]; complex results interleaved. No all-reduce, no sync.
+int mxg_dev_dot(mxg_ctx* ctx, const MvDesc& A, const MvDesc& B, double* d_out);
+
+inline int mxg_grid_for(int64_t n, int block, int per_thread, int cap) {
+  int64_t g = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+#endif

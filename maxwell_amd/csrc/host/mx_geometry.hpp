@@ -1,0 +1,147 @@
+// Level-set shapes and cut-cell fractions used by the Dey-Mittra operators (host side, setup).
+//
+// Restates the geometry rules of the reference that fix the assembled pencil:
+//   shapes      src/MxShape.hpp:145-172, src/MxShape.cpp:91-205 (affine transforms),
+//               src/MxCylinder.hpp:34-40, src/MxSphere.hpp:31-33, src/MxHalfSpace.hpp:31-33,
+//               src/MxSlab.hpp:95-100,132-138, src/MxShapeIntersection.hpp:122-136,186-206
+//   sign()      src/MxUtil.hpp:26,44-49 (dEps = 0)
+//   rootFind    src/MxUtil.hpp:297-362 (maxiter overwritten with 500)
+//   segment     src/MxSegment.cpp:21-42
+//   polygon     src/MxPolytope.cpp:8-80, src/MxConvexPolygon.cpp:24-76,165-252,256-291,
+//               src/MxCartRect.hpp:37-91
+//   polyhedron  src/MxConvexPolyhedron.cpp:66-346, src/MxCartBox.cpp:22-62, src/MxCartBox.hpp:33-47
+#ifndef MX_GEOMETRY_HPP
+#define MX_GEOMETRY_HPP
+
+#include <array>
+#include <cmath>
+#include <limits>
+#include <memory>
+#include <vector>
+
+namespace mx {
+
+struct Vec3 {
+  double v[3];
+  Vec3() : v{0, 0, 0} {}
+  Vec3(double a, double b, double c) : v{a, b, c} {}
+  double& operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+};
+inline Vec3 operator+(const Vec3& a, const Vec3& b) { return Vec3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+inline Vec3 operator-(const Vec3& a, const Vec3& b) { return Vec3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+inline Vec3 operator*(const Vec3& a, double s) { return Vec3(a[0] * s, a[1] * s, a[2] * s); }
+inline Vec3 operator*(double s, const Vec3& a) { return Vec3(a[0] * s, a[1] * s, a[2] * s); }
+inline double dot(const Vec3& a, const Vec3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double norm(const Vec3& a) { return std::sqrt(dot(a, a)); }
+inline Vec3 cross(const Vec3& a, const Vec3& b) {
+  return Vec3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+}
+inline int sgn(double x) { return x < 0.0 ? -1 : (x == 0.0 ? 0 : 1); }
+
+struct Mat3 {
+  double a[3][3];
+  static Mat3 eye() { Mat3 m{}; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.a[i][j] = i == j; return m; }
+  Vec3 mul(const Vec3& p) const {
+    return Vec3(a[0][0] * p[0] + a[0][1] * p[1] + a[0][2] * p[2],
+                a[1][0] * p[0] + a[1][1] * p[1] + a[1][2] * p[2],
+                a[2][0] * p[0] + a[2][1] * p[1] + a[2][2] * p[2]);
+  }
+  Vec3 lmul(const Vec3& g) const {  // row vector times matrix
+    return Vec3(g[0] * a[0][0] + g[1] * a[1][0] + g[2] * a[2][0],
+                g[0] * a[0][1] + g[1] * a[1][1] + g[2] * a[2][1],
+                g[0] * a[0][2] + g[1] * a[1][2] + g[2] * a[2][2]);
+  }
+};
+Mat3 matmul(const Mat3& x, const Mat3& y);
+Mat3 inverse(const Mat3& m);
+
+// func(p) > 0 inside; func = sign * _func(Ainv p - Ainv b)
+class Shape {
+ public:
+  Shape();
+  virtual ~Shape() {}
+  double func(const Vec3& p) const { return sign_ * localFunc(Ainv_.mul(p) - Ainvb_); }
+  Vec3 gradFunc(const Vec3& p) const { return sign_ * Ainv_.lmul(localGrad(Ainv_.mul(p) - Ainvb_)); }
+  void translate(const Vec3& v);
+  void rotate(const Vec3& axis, double angle, const Vec3& pivot);
+  void scale(const Vec3& magnitudes, const Vec3& origin);
+  void reflect(const Vec3& normal, const Vec3& pointInPlane);
+  void invert() { sign_ *= -1.0; }
+  const Vec3& translation() const { return b_; }
+
+ protected:
+  virtual double localFunc(const Vec3& q) const = 0;
+  virtual Vec3 localGrad(const Vec3& q) const = 0;
+
+ private:
+  double sign_;
+  Mat3 A_, Ainv_;
+  Vec3 b_, Ainvb_;
+};
+
+class HalfSpace : public Shape {
+ public:
+  HalfSpace(const Vec3& pointInPlane, const Vec3& normal);
+ protected:
+  double localFunc(const Vec3& q) const override { return dot(n_, q); }
+  Vec3 localGrad(const Vec3&) const override { return n_; }
+ private:
+  Vec3 n_;
+};
+
+class Cylinder : public Shape {
+ public:
+  Cylinder(double radius, const Vec3& axis, const Vec3& location);
+ protected:
+  double localFunc(const Vec3& q) const override { return r2_ - dot(q, P_.mul(q)); }
+  Vec3 localGrad(const Vec3& q) const override { return -2.0 * P_.mul(q); }
+ private:
+  double r2_;
+  Mat3 P_;
+};
+
+class Sphere : public Shape {
+ public:
+  Sphere(double radius, const Vec3& location);
+ protected:
+  double localFunc(const Vec3& q) const override { return 1.0 - dot(q, q) / r2_; }
+  Vec3 localGrad(const Vec3& q) const override {   // -2.0 * p / r2, left to right
+    return Vec3(-2.0 * q[0] / r2_, -2.0 * q[1] / r2_, -2.0 * q[2] / r2_);
+  }
+ private:
+  double r2_;
+};
+
+class ShapeIntersection : public Shape {
+ public:
+  ShapeIntersection() {}
+  void add(std::shared_ptr<const Shape> s) { shapes_.push_back(std::move(s)); }
+ protected:
+  double localFunc(const Vec3& q) const override;
+  Vec3 localGrad(const Vec3& q) const override;
+ private:
+  std::vector<std::shared_ptr<const Shape>> shapes_;
+};
+
+class Slab : public Shape {
+ public:
+  Slab(double thickness, const Vec3& normal, const Vec3& midplanePoint);
+ protected:
+  double localFunc(const Vec3& q) const override { return slab_.func(q); }
+  Vec3 localGrad(const Vec3& q) const override { return slab_.gradFunc(q); }
+ private:
+  ShapeIntersection slab_;
+};
+
+Vec3 rootFind(const Shape& shape, const Vec3& p1, const Vec3& p2, double tol = 1.e-12);
+
+// fraction of a Cartesian segment (centre `mid`, direction `axis`, length `len`) inside the shape
+double segmentFraction(const Shape& shape, const Vec3& mid, int axis, double len);
+// fraction of a Cartesian rectangle with normal `axis`, side l1 along axis+1, l2 along axis+2
+double rectFraction(const Shape& shape, const Vec3& center, int axis, double l1, double l2);
+// fraction of a Cartesian box
+double boxFraction(const Shape& shape, const Vec3& center, double lx, double ly, double lz);
+
+}  // namespace mx
+#endif

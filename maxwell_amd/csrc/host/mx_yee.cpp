@@ -1,0 +1,476 @@
+// See mx_yee.hpp for the reference lines each routine follows.
+#include "mx_yee.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace mx {
+
+namespace {
+struct Tick {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  bool on = std::getenv("MXH_VERBOSE") != nullptr;
+  void operator()(const char* what) {
+    auto now = std::chrono::steady_clock::now();
+    if (on) std::fprintf(stderr, "[mx_yee] %-12s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+    t = now;
+  }
+};
+}  // namespace
+
+BcKind parseBc(const std::string& s) {
+  if (s == "periodic") return BC_PERIODIC;
+  if (s == "pec") return BC_PEC;
+  if (s == "pmc") return BC_PMC;
+  throw std::runtime_error("unknown boundary condition '" + s + "'");
+}
+
+template <> double YeeAssembler<double>::toScalar(const std::complex<double>& z) { return z.real(); }
+template <> std::complex<double> YeeAssembler<std::complex<double>>::toScalar(const std::complex<double>& z) { return z; }
+
+template <typename S>
+YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
+  complexProblem_ = false;
+  for (int i = 0; i < 3; ++i) {
+    n_[i] = cfg.n[i];
+    d_[i] = cfg.size[i] / double(cfg.n[i]);                    // src/MxGrid.cpp:18
+    phase_[i] = std::exp(std::complex<double>(0.0, 1.0) * cfg.phaseShifts[i]);  // src/MxGridField.cpp:34-38
+    if (cfg.phaseShifts[i] != 0.0) complexProblem_ = true;
+  }
+  if (complexProblem_ && sizeof(S) == sizeof(double))
+    throw std::runtime_error("phase shifts need the complex assembler");
+  B_.name = "bfield"; E_.name = "efield"; P_.name = "psifield";
+  B_.ncomp = 3; E_.ncomp = 3; P_.ncomp = 1;
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 3; ++i) {
+      B_.xi0[c][i] = (i == c);   // face centre: 0 along the normal, d/2 elsewhere
+      E_.xi0[c][i] = (i != c);   // edge centre: d/2 along the edge, 0 elsewhere
+      P_.xi0[c][i] = false;      // cell centre
+    }
+  auto compBc = [](BcKind b, bool normal, bool isB) -> int {
+    if (b == BC_PERIODIC) return CBC_PERIODIC;
+    // B: PEC -> normal ZERO / tangential CONSTANT; E the opposite; PMC swaps
+    const bool zero = (b == BC_PEC) ? (isB ? normal : !normal) : (isB ? !normal : normal);
+    return zero ? CBC_ZERO : CBC_CONSTANT;
+  };
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 3; ++i) {
+      B_.lbc[c][i] = compBc(cfg.lower[i], i == c, true);
+      B_.ubc[c][i] = compBc(cfg.upper[i], i == c, true);
+      E_.lbc[c][i] = compBc(cfg.lower[i], i == c, false);
+      E_.ubc[c][i] = compBc(cfg.upper[i], i == c, false);
+    }
+  for (int i = 0; i < 3; ++i) {
+    auto psiBc = [](BcKind b) { return b == BC_PERIODIC ? CBC_PERIODIC : (b == BC_PEC ? CBC_CONSTANT : CBC_ZERO); };
+    P_.lbc[0][i] = psiBc(cfg.lower[i]);
+    P_.ubc[0][i] = psiBc(cfg.upper[i]);
+  }
+  Tick tick;
+  if (cfg_.pec) {
+    addShapeRep(B_);
+    addShapeRep(E_);
+    addShapeRep(P_);
+  }
+  tick("fractions");
+  // "any used component keeps the whole B cell" lookup over the extended lattice
+  const int64_t next = (int64_t)(n_[0] + 3) * (n_[1] + 3) * (n_[2] + 3);
+  bcellUsed_.resize(next);
+#pragma omp parallel for schedule(static)
+  for (int i = -1; i <= n_[0] + 1; ++i)
+    for (int j = -1; j <= n_[1] + 1; ++j)
+      for (int k = -1; k <= n_[2] + 1; ++k) {
+        const int c[3] = {i, j, k};
+        bcellUsed_[extIndex(c)] = baseUse(B_, 0, c) || baseUse(B_, 1, c) || baseUse(B_, 2, c);
+      }
+  tick("bcellUsed");
+  setMap(B_);
+  setMap(E_);
+  setMap(P_);
+  tick("maps");
+}
+
+template <typename S>
+int64_t YeeAssembler<S>::cellToGlobal(const int c[3]) const {   // src/MxGrid.h:98-113
+  int64_t res = 0, f = 1;
+  for (int i = 2; i >= 0; --i) {
+    const int ni = n_[i] + 1;
+    int g = c[i];
+    if (g >= ni) g -= ni; else if (g < 0) g += ni;
+    res += (int64_t)g * f;
+    f *= ni;
+  }
+  return res;
+}
+
+template <typename S>
+void YeeAssembler<S>::globalToCell(int64_t idx, int c[3]) const {  // src/MxGrid.h:116-127
+  int64_t f = 1;
+  for (int i = 2; i >= 0; --i) {
+    const int ni = n_[i] + 1;
+    c[i] = (int)((idx / f) % ni);
+    f *= ni;
+  }
+}
+
+template <typename S>
+void YeeAssembler<S>::interior(const YeeField& F, int comp, const int c[3], int out[3]) const {
+  // getInteriorComp, src/MxGridField.cpp:80-142; case 1 is a stand-alone `if`, so for cell < 0
+  // case 2 always has the last word
+  for (int i = 0; i < 3; ++i) {
+    const int lbc = F.lbc[comp][i], ubc = F.ubc[comp][i];
+    const bool xi0 = F.xi0[comp][i];
+    const int ci = c[i], ni = n_[i];
+    int o = ci;
+    if (ci < 0) {
+      o = (lbc == CBC_PERIODIC) ? ni + ci : -ci - 1;
+    } else if (ci == ni && xi0) {
+      if (ubc == CBC_PERIODIC) o = 0;
+    } else if (ci >= ni && xi0) {
+      o = (ubc == CBC_PERIODIC) ? ci - ni : ni - (ci - ni);
+    } else if (ci >= ni) {
+      o = (ubc == CBC_PERIODIC) ? ci - ni : ni - (ci - ni + 1);
+    }
+    out[i] = o;
+  }
+}
+
+template <typename S>
+double YeeAssembler<S>::fracAt(const YeeField& F, int comp, const int c[3]) const {
+  if (F.frac.empty()) return 1.0;                             // src/MxGridField.hpp:274-277
+  return F.frac[comp][extIndex(c)];
+}
+
+template <typename S>
+void YeeAssembler<S>::addShapeRep(YeeField& F) {               // src/MxGridField.cpp:193-226
+  const Shape& shape = *cfg_.pec;
+  const int64_t next = (int64_t)(n_[0] + 3) * (n_[1] + 3) * (n_[2] + 3);
+  F.frac.assign(F.ncomp, UVec<double>());
+  for (int comp = 0; comp < F.ncomp; ++comp) {
+    UVec<double>& fr = F.frac[comp];
+    fr.resize(next);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = -1; i <= n_[0] + 1; ++i)
+      for (int j = -1; j <= n_[1] + 1; ++j)
+        for (int k = -1; k <= n_[2] + 1; ++k) {
+          const int c[3] = {i, j, k};
+          int ic[3];
+          interior(F, comp, c, ic);
+          Vec3 p;                                              // calcCompFrac, src/MxGridField.hpp:177-183
+          for (int a = 0; a < 3; ++a)
+            p[a] = (cfg_.origin[a] + double(ic[a]) * d_[a]) + (F.xi0[comp][a] ? 0.0 : 0.5 * d_[a]);
+          double f;
+          if (&F == &B_) f = rectFraction(shape, p, comp, d_[(comp + 1) % 3], d_[(comp + 2) % 3]);
+          else if (&F == &E_) f = segmentFraction(shape, p, comp, d_[comp]);
+          else f = boxFraction(shape, p, d_[0], d_[1], d_[2]);
+          fr[extIndex(c)] = f;
+        }
+  }
+}
+
+template <typename S>
+bool YeeAssembler<S>::baseUse(const YeeField& F, int comp, const int c[3]) const {
+  // MxGridField::useCompInMap, src/MxGridField.cpp:41-77
+  if (!F.frac.empty() && fracAt(F, comp, c) == 0.0) return false;
+  for (int i = 0; i < 3; ++i) {
+    const bool xi0 = F.xi0[comp][i];
+    if (c[i] == 0 && xi0) {
+      if (F.lbc[comp][i] == CBC_ZERO) return false;
+    } else if (c[i] == n_[i] && !xi0) {
+      return false;
+    } else if (c[i] == n_[i] && xi0) {
+      if (F.ubc[comp][i] == CBC_ZERO || F.ubc[comp][i] == CBC_PERIODIC) return false;
+    }
+  }
+  return true;
+}
+
+template <typename S>
+bool YeeAssembler<S>::bUse(const int c[3]) const {             // src/MxYeeFitBField.cpp:63-80
+  return bcellUsed_[extIndex(c)] != 0;
+}
+
+template <typename S>
+bool YeeAssembler<S>::eUse(int comp, const int c[3]) const {   // src/MxYeeFitEField.cpp:53-88
+  if (!baseUse(E_, comp, c)) return false;
+  const int c2 = (comp + 1) % 3, c3 = (comp + 2) % 3;
+  int t[3] = {c[0], c[1], c[2]};
+  if (!bUse(t)) return false;
+  t[c3]--; if (!bUse(t)) return false; t[c3]++;
+  t[c2]--; if (!bUse(t)) return false;
+  return true;
+}
+
+template <typename S>
+bool YeeAssembler<S>::psiUse(const int c[3]) const {           // src/MxYeePsiField.cpp:100-114
+  if (!baseUse(P_, 0, c)) return false;
+  int t[3] = {c[0], c[1], c[2]};
+  for (int i = 0; i < 3; ++i) {
+    if (bUse(t)) return true;
+    t[i]++; if (bUse(t)) return true; t[i]--;
+  }
+  return false;
+}
+
+template <typename S>
+bool YeeAssembler<S>::use(const YeeField& F, int comp, const int c[3]) const {
+  if (&F == &B_) return bUse(c);
+  if (&F == &E_) return eUse(comp, c);
+  return psiUse(c);
+}
+
+template <typename S>
+std::complex<double> YeeAssembler<S>::baseFactor(const YeeField& F, int comp, const int c[3]) const {
+  // MxGridField::getCompFactor, src/MxGridField.cpp:145-190
+  if (!F.frac.empty() && fracAt(F, comp, c) == 0.0) return 0.0;
+  std::complex<double> res(1.0, 0.0);
+  for (int i = 0; i < 3; ++i) {
+    const int lbc = F.lbc[comp][i], ubc = F.ubc[comp][i];
+    const bool xi0 = F.xi0[comp][i];
+    if (c[i] < 0) {
+      if (lbc == CBC_PERIODIC) res /= phase_[i];
+      else if (lbc == CBC_ZERO) res *= -1.0;
+    } else if (c[i] == 0 && xi0) {
+      if (lbc == CBC_ZERO) res *= 0.0;
+    } else if (c[i] == n_[i] && xi0) {
+      if (ubc == CBC_PERIODIC) res *= phase_[i];
+      else if (ubc == CBC_ZERO) res *= 0.0;
+    } else if (c[i] >= n_[i]) {
+      if (ubc == CBC_PERIODIC) res *= phase_[i];
+      else if (ubc == CBC_ZERO) res *= -1.0;
+    }
+  }
+  return res;
+}
+
+template <typename S>
+std::complex<double> YeeAssembler<S>::factor(const YeeField& F, int comp, const int c[3]) const {
+  const std::complex<double> res = baseFactor(F, comp, c);
+  if (&F == &B_) return res;                                   // src/MxYeeFitBField.cpp:83-90 (dmFrac 0)
+  int probe[3] = {c[0], c[1], c[2]};
+  if (!cfg_.strict) interior(F, comp, c, probe);
+  return use(F, comp, probe) ? res : std::complex<double>(0.0);  // src/MxYeeFitEField.cpp:91-98, MxYeePsiField.cpp:117-124
+}
+
+template <typename S>
+int64_t YeeAssembler<S>::gid(const YeeField& F, int comp, const int c[3]) const {
+  int ic[3];
+  interior(F, comp, c, ic);
+  return comp + (int64_t)F.ncomp * cellToGlobal(ic);           // src/MxGridField.hpp:142-145
+}
+
+template <typename S>
+void YeeAssembler<S>::setMap(YeeField& F) {                     // src/MxGridField.cpp:256-297
+  const int64_t nnode = (int64_t)(n_[0] + 1) * (n_[1] + 1) * (n_[2] + 1);
+  F.lidOfGid.resize(nnode * F.ncomp);
+  UVec<uint8_t> keep(nnode * F.ncomp);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i <= n_[0]; ++i)
+    for (int j = 0; j <= n_[1]; ++j)
+      for (int k = 0; k <= n_[2]; ++k) {
+        const int c[3] = {i, j, k};
+        const int64_t g = cellToGlobal(c);
+        for (int comp = 0; comp < F.ncomp; ++comp) keep[g * F.ncomp + comp] = use(F, comp, c);
+      }
+  int64_t count = 0;
+  for (int64_t g = 0; g < nnode * F.ncomp; ++g) count += keep[g];
+  F.gids.resize(count);
+  count = 0;
+  for (int64_t g = 0; g < nnode * F.ncomp; ++g) {
+    if (keep[g]) { F.lidOfGid[g] = (int32_t)count; F.gids[count++] = g; }
+    else F.lidOfGid[g] = -1;
+  }
+}
+
+template <typename S>
+Csr<S> YeeAssembler<S>::assemble(const YeeField& rowF, const YeeField& colF, bool skipDeadRows,
+                                 const std::vector<std::vector<Entry>>& stencil) const {
+  const int64_t nrows = (int64_t)rowF.gids.size();
+  size_t maxe = 0;
+  for (auto& s : stencil) maxe = std::max(maxe, s.size());
+  UVec<int32_t> cols(nrows * maxe);
+  UVec<S> vals(nrows * maxe);
+  UVec<int32_t> cnt(nrows);
+  bool bad = false;
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int64_t g = rowF.gids[r];
+    const int comp = (int)(g % rowF.ncomp);
+    int cell[3];
+    globalToCell(g / rowF.ncomp, cell);
+    if (skipDeadRows && factor(rowF, comp, cell) == std::complex<double>(0.0)) { cnt[r] = 0; continue; }
+    int n = 0;
+    for (const Entry& e : stencil[comp]) {
+      const int c[3] = {cell[0] + e.off[0], cell[1] + e.off[1], cell[2] + e.off[2]};
+      const std::complex<double> f = factor(colF, e.comp, c);
+      if (f == std::complex<double>(0.0)) continue;           // `if (factors[i] != 0)` in every assembler
+      const int32_t lid = colF.lidOfGid[gid(colF, e.comp, c)];
+      if (lid < 0) { bad = true; continue; }
+      cols[r * maxe + n] = lid;
+      vals[r * maxe + n] = toScalar(f) * S(e.val);
+      ++n;
+    }
+    cnt[r] = n;
+  }
+  if (bad) throw std::runtime_error("assemble: column outside the domain map (" + rowF.name + " x " + colF.name + ")");
+  // rows are short: sort each by column and sum repeated (row, col) pairs in insertion order,
+  // as Epetra's FillComplete does (only reachable on 2-cell periodic directions)
+  Csr<S> m;
+  m.nrows = nrows; m.ncols = (int64_t)colF.gids.size();
+  m.rowptr.resize(nrows + 1); m.rowptr[0] = 0;
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < nrows; ++r) {
+    int32_t* c = cols.data() + r * maxe;
+    S* v = vals.data() + r * maxe;
+    int n = cnt[r];
+    for (int x = 1; x < n; ++x) {
+      const int32_t cc = c[x]; const S vv = v[x];
+      int y = x - 1;
+      while (y >= 0 && c[y] > cc) { c[y + 1] = c[y]; v[y + 1] = v[y]; --y; }
+      c[y + 1] = cc; v[y + 1] = vv;
+    }
+    int w = 0;
+    for (int x = 0; x < n; ++x) {
+      if (w > 0 && c[w - 1] == c[x]) v[w - 1] += v[x];
+      else { c[w] = c[x]; v[w] = v[x]; ++w; }
+    }
+    cnt[r] = w;
+  }
+  for (int64_t r = 0; r < nrows; ++r) m.rowptr[r + 1] = m.rowptr[r] + cnt[r];
+  m.col.resize(m.rowptr[nrows]);
+  m.val.resize(m.rowptr[nrows]);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < nrows; ++r) {
+    std::copy(cols.begin() + r * maxe, cols.begin() + r * maxe + cnt[r], m.col.begin() + m.rowptr[r]);
+    std::copy(vals.begin() + r * maxe, vals.begin() + r * maxe + cnt[r], m.val.begin() + m.rowptr[r]);
+  }
+  return m;
+}
+
+template <typename S>
+Csr<S> YeeAssembler<S>::curlE() const {                        // src/MxYeeDeyMittraCurlE.cpp:117-179
+  std::vector<std::vector<Entry>> st(3);
+  for (int c0 = 0; c0 < 3; ++c0) {
+    const int c1 = (c0 + 1) % 3, c2 = (c0 + 2) % 3;
+    Entry e0{c2, {0, 0, 0}, 1.0 / d_[c1]}; e0.off[c1] = 1;
+    Entry e1{c2, {0, 0, 0}, -(1.0 / d_[c1])};
+    Entry e2{c1, {0, 0, 0}, -(1.0 / d_[c2])}; e2.off[c2] = 1;
+    Entry e3{c1, {0, 0, 0}, 1.0 / d_[c2]};
+    st[c0] = {e0, e1, e2, e3};
+  }
+  return assemble(B_, E_, true, st);
+}
+
+template <typename S>
+Csr<S> YeeAssembler<S>::curlB() const {                        // src/MxYeeDeyMittraCurlB.cpp:113-169
+  std::vector<std::vector<Entry>> st(3);
+  for (int c0 = 0; c0 < 3; ++c0) {
+    const int c1 = (c0 + 1) % 3, c2 = (c0 + 2) % 3;
+    Entry e0{c2, {0, 0, 0}, 1.0 / d_[c1]};
+    Entry e1{c2, {0, 0, 0}, -(1.0 / d_[c1])}; e1.off[c1] = -1;
+    Entry e2{c1, {0, 0, 0}, -(1.0 / d_[c2])};
+    Entry e3{c1, {0, 0, 0}, 1.0 / d_[c2]}; e3.off[c2] = -1;
+    st[c0] = {e0, e1, e2, e3};
+  }
+  return assemble(E_, B_, false, st);
+}
+
+template <typename S>
+Csr<S> YeeAssembler<S>::divB() const {                         // src/MxYeeDeyMittraDivB.cpp:157-200
+  std::vector<std::vector<Entry>> st(1);
+  for (int c = 0; c < 3; ++c) {
+    Entry a{c, {0, 0, 0}, 1.0 / d_[c]}; a.off[c] = 1;
+    Entry b{c, {0, 0, 0}, -1.0 / d_[c]};
+    st[0].push_back(a);
+    st[0].push_back(b);
+  }
+  return assemble(P_, B_, false, st);
+}
+
+template <typename S>
+Csr<S> YeeAssembler<S>::gradPsi() const {                      // src/MxYeeDeyMittraGradPsi.cpp:23-84
+  std::vector<std::vector<Entry>> st(3);
+  for (int c = 0; c < 3; ++c) {
+    const double inv = 1.0 / d_[c];
+    Entry a{0, {0, 0, 0}, inv};
+    Entry b{0, {0, 0, 0}, -inv}; b.off[c] = -1;
+    st[c] = {a, b};
+  }
+  return assemble(B_, P_, true, st);
+}
+
+template <typename S>
+Csr<S> YeeAssembler<S>::fracs(const YeeField& F, bool inverse) const {   // src/MxYeeDeyMittraFracs.cpp:30-131
+  UVec<S> d(F.gids.size());
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < (int64_t)F.gids.size(); ++r) {
+    const int64_t g = F.gids[r];
+    int cell[3];
+    globalToCell(g / F.ncomp, cell);
+    double v = fracAt(F, (int)(g % F.ncomp), cell);
+    if (inverse) v = (v == 0.0) ? 0.0 : 1.0 / v;
+    d[r] = S(v);
+  }
+  return diagonal<S>(d);
+}
+
+template <typename S>
+std::vector<double> YeeAssembler<S>::usedMask() const {
+  std::vector<double> m(B_.gids.size());
+  for (int64_t r = 0; r < (int64_t)B_.gids.size(); ++r) {
+    const int64_t g = B_.gids[r];
+    int cell[3];
+    globalToCell(g / 3, cell);
+    m[r] = factor(B_, (int)(g % 3), cell) == std::complex<double>(0.0) ? 0.0 : 1.0;
+  }
+  return m;
+}
+
+template <typename S>
+Csr<S> YeeAssembler<S>::multiplyOps(const std::map<std::string, Csr<S>>& ops,
+                                    const std::vector<std::string>& names) {
+  Csr<S> res = ops.at(names[0]);
+  for (size_t i = 1; i < names.size(); ++i) res = multiply(ops.at(names[i]), res);
+  return res;
+}
+
+template <typename S>
+std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps() const {   // src/MxMagWaveOp.cpp:138-245
+  std::map<std::string, Csr<S>> o;
+  Tick tick;
+  o["curlE"] = curlE();
+  o["curlB"] = curlB();
+  o["divB"] = divB();
+  o["gradPsi"] = gradPsi();
+  const bool pec = hasPec();
+  if (pec) {
+    o["dmA"] = fracs(B_, false);
+    o["dmL"] = fracs(E_, false);
+    o["dmVInv"] = fracs(P_, true);
+  }
+  tick("primitives");
+  auto opt = [&](std::vector<std::string>& v, const char* nm) { if (pec) v.push_back(nm); };
+  std::vector<std::string> names;
+  names = {"curlB"}; opt(names, "dmL"); names.push_back("curlE");
+  o["curlCurl"] = multiplyOps(o, names);                                   // :145-153
+  names.clear(); opt(names, "dmA"); names.push_back("divB"); opt(names, "dmVInv");
+  names.push_back("gradPsi"); opt(names, "dmA");
+  o["gradDiv"] = multiplyOps(o, names);                                    // :156-179
+  tick("products");
+  o["vecLapl"] = purge(add(o["curlCurl"], S(1.0), o["gradDiv"], S(-1.0)));  // :183-193
+  tick("vecLapl");
+  names = {"gradPsi"}; opt(names, "dmA"); names.push_back("divB");
+  Csr<S> sl = multiplyOps(o, names);                                       // :208-220
+  scaleInPlace(sl, S(-1.0));
+  o["scaLapl"] = sl;
+  if (pec) o["mRhs"] = o["dmA"];                                           // :233-236
+  else o["mRhs"] = diagonal<S>(UVec<S>(B_.gids.size(), S(1.0)));    // :240-241
+  return o;
+}
+
+template class YeeAssembler<double>;
+template class YeeAssembler<std::complex<double>>;
+
+}  // namespace mx

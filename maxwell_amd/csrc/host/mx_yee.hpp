@@ -1,0 +1,123 @@
+// Yee / Dey-Mittra operator assembly on the host (setup; feeds the GPU hot path).
+//
+// Restates, for 3-D, the semantics of
+//   lattice / indices   src/MxGrid.h:96-128, src/MxGrid.cpp:100-193, src/MxGridDomain.cpp:21-89
+//   field layouts       src/MxYeeMagFieldBase.cpp:85-116, src/MxYeeElecFieldBase.cpp:64-82,
+//                       src/MxYeePsiField.cpp:50-70
+//   BC translation      src/MxYeeMagFieldBase.cpp:119-168, src/MxYeeElecFieldBase.cpp:89-138,
+//                       src/MxYeePsiField.cpp:73-96
+//   map membership      src/MxGridField.cpp:41-77,256-297, src/MxYeeFitBField.cpp:63-80,
+//                       src/MxYeeFitEField.cpp:53-88, src/MxYeePsiField.cpp:100-114
+//   BC mirroring/phase  src/MxGridField.cpp:80-190, src/MxYeeFitBField.cpp:83-90,
+//                       src/MxYeeFitEField.cpp:91-98, src/MxYeePsiField.cpp:117-124
+//   fractions           src/MxGridField.hpp:177-183, src/MxGridField.cpp:193-226
+//   operators           src/MxYeeDeyMittraCurlE.cpp:117-179, CurlB.cpp:113-169, DivB.cpp:157-200,
+//                       GradPsi.cpp:23-84, Fracs.cpp:30-131
+//   products            src/MxMagWaveOp.cpp:138-273, src/MxEMOps.cpp:197-268, src/MxUtil.cpp:318-371
+// as one assembler object instead of the reference's class-per-operator hierarchy: the hot
+// path only consumes the finished CSR arrays.
+#ifndef MX_YEE_HPP
+#define MX_YEE_HPP
+
+#include <complex>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mx_geometry.hpp"
+#include "mx_sparse.hpp"
+
+namespace mx {
+
+enum BcKind { BC_PERIODIC = 0, BC_PEC = 1, BC_PMC = 2 };          // user-level (MxTypes.h)
+enum CompBc { CBC_PERIODIC = 0, CBC_ZERO = 1, CBC_CONSTANT = 2 };  // per component and axis
+
+struct YeeConfig {
+  int n[3] = {16, 16, 16};
+  double origin[3] = {0, 0, 0};
+  double size[3] = {1, 1, 1};
+  BcKind lower[3] = {BC_PERIODIC, BC_PERIODIC, BC_PERIODIC};
+  BcKind upper[3] = {BC_PERIODIC, BC_PERIODIC, BC_PERIODIC};
+  double phaseShifts[3] = {0, 0, 0};
+  std::shared_ptr<const Shape> pec;   // null: no PEC region
+  // true: keep the reference's behaviour of testing useCompInMap on the un-interiorised cell in
+  // MxYeeFitEField/MxYeePsiField::getCompFactor (drops periodic wrap entries of curlE at the
+  // upper boundary); false: test the interiorised cell
+  bool strict = true;
+};
+
+struct YeeField {
+  std::string name;
+  int ncomp = 0;
+  bool xi0[3][3];                 // cell-relative coordinate == 0 along axis i for component c
+  int lbc[3][3], ubc[3][3];       // CompBc per component and axis
+  std::vector<UVec<double>> frac;   // per component over the extended lattice; empty: no region
+  UVec<int64_t> gids;             // sorted global ids of the map
+  UVec<int32_t> lidOfGid;         // dense lookup over ncomp * (N+1)^3, -1 if absent
+};
+
+template <typename S>
+class YeeAssembler {
+ public:
+  explicit YeeAssembler(const YeeConfig& cfg);
+
+  const YeeField& bfield() const { return B_; }
+  const YeeField& efield() const { return E_; }
+  const YeeField& psifield() const { return P_; }
+  bool hasPec() const { return (bool)cfg_.pec; }
+  const YeeConfig& config() const { return cfg_; }
+  double cellSize(int i) const { return d_[i]; }
+
+  // primitive operators (MxEMOps::setSingleOps)
+  Csr<S> curlE() const;
+  Csr<S> curlB() const;
+  Csr<S> divB() const;
+  Csr<S> gradPsi() const;
+  Csr<S> fracs(const YeeField& F, bool inverse) const;
+
+  // name -> matrix: curlE curlB divB gradPsi [dmA dmL dmVInv] curlCurl gradDiv vecLapl scaLapl mRhs
+  std::map<std::string, Csr<S>> waveOps() const;
+  // massiveCrsMultiply order: first name applied first, m_k * (... * (m_1 * m_0))
+  static Csr<S> multiplyOps(const std::map<std::string, Csr<S>>& ops,
+                            const std::vector<std::string>& names);
+
+  // rows of the B map whose own component factor is zero (empty rows of curlE / gradPsi)
+  std::vector<double> usedMask() const;
+  int64_t cellToGlobal(const int c[3]) const;
+  void globalToCell(int64_t idx, int c[3]) const;
+
+ private:
+  YeeConfig cfg_;
+  int n_[3];
+  double d_[3];
+  std::complex<double> phase_[3];
+  bool complexProblem_;
+  YeeField B_, E_, P_;
+  UVec<uint8_t> bcellUsed_;  // extended lattice
+
+  int64_t extIndex(const int c[3]) const {
+    return ((int64_t)(c[0] + 1) * (n_[1] + 3) + (c[1] + 1)) * (n_[2] + 3) + (c[2] + 1);
+  }
+  void interior(const YeeField& F, int comp, const int c[3], int out[3]) const;
+  double fracAt(const YeeField& F, int comp, const int c[3]) const;
+  bool baseUse(const YeeField& F, int comp, const int c[3]) const;
+  bool bUse(const int c[3]) const;
+  bool eUse(int comp, const int c[3]) const;
+  bool psiUse(const int c[3]) const;
+  bool use(const YeeField& F, int comp, const int c[3]) const;
+  std::complex<double> baseFactor(const YeeField& F, int comp, const int c[3]) const;
+  std::complex<double> factor(const YeeField& F, int comp, const int c[3]) const;
+  int64_t gid(const YeeField& F, int comp, const int c[3]) const;
+  void addShapeRep(YeeField& F);
+  void setMap(YeeField& F);
+  struct Entry { int comp; int off[3]; double val; };
+  Csr<S> assemble(const YeeField& rowF, const YeeField& colF, bool skipDeadRows,
+                  const std::vector<std::vector<Entry>>& stencilPerRowComp) const;
+  static S toScalar(const std::complex<double>& z);
+};
+
+BcKind parseBc(const std::string& s);
+
+}  // namespace mx
+#endif

@@ -1,0 +1,26 @@
+// Internal definitions shared by the mxh_* C ABI translation units.
+#ifndef MXH_INTERNAL_HPP
+#define MXH_INTERNAL_HPP
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mx_yee.hpp"
+#include "mxh.h"
+
+struct mxh_sim {
+  mx::YeeConfig cfg;
+  std::unique_ptr<mx::YeeAssembler<double>> asmb;
+  std::map<std::string, mx::Csr<double>> ops;
+  std::map<double, mx::Csr<double>> shifted;
+  std::vector<double> mask;
+  double setup_seconds = 0.0;
+};
+
+void mxh_set_error(const std::string& s);
+std::shared_ptr<const mx::Shape> mxh_parse_shape(const char* spec);
+const mx::Csr<double>& mxh_sim_shifted_matrix(mxh_sim* s, double shift);
+
+#endif

@@ -392,23 +392,32 @@ class YeeSim:
             ops["dmVInv"] = self.fracs(self.P, inverse=True)
         return ops
 
+    @staticmethod
+    def multiply_ops(ops, names):
+        """MxEMOps::multiplyOps -> MxUtil::Trilinos::massiveCrsMultiply (src/MxEMOps.cpp:197-225,
+        src/MxUtil.cpp:318-371): the first name is applied first and the product is built as
+        m_k * ( ... * (m_1 * m_0)), each step a full SpGEMM."""
+        res = ops[names[0]]
+        for nm in names[1:]:
+            res = (ops[nm] @ res).tocsr()
+            res.sum_duplicates()
+            res.sort_indices()
+        return res
+
     def wave_ops(self):
-        """MxMagWaveOp::initMatrices, src/MxMagWaveOp.cpp:138-245.  multiplyOps applies the
-        first name first (src/MxEMOps.h:61-66), i.e. the product is last * ... * first."""
+        """MxMagWaveOp::initMatrices, src/MxMagWaveOp.cpp:138-245."""
         o = self.single_ops()
         has_pec = self.pec is not None
+        pec = lambda name: [name] if has_pec else []
+        curlcurl = self.multiply_ops(o, ["curlB"] + pec("dmL") + ["curlE"])                 # :145-153
+        graddiv = self.multiply_ops(o, pec("dmA") + ["divB"] + pec("dmVInv") + ["gradPsi"] + pec("dmA"))  # :156-179
+        scalapl = -self.multiply_ops(o, ["gradPsi"] + pec("dmA") + ["divB"])                # :208-220
         if has_pec:
-            curlcurl = o["curlE"] @ o["dmL"] @ o["curlB"]                       # :145-153
-            graddiv = o["dmA"] @ o["gradPsi"] @ o["dmVInv"] @ o["divB"] @ o["dmA"]   # :156-179
-            scalapl = -(o["divB"] @ o["dmA"] @ o["gradPsi"])                   # :208-220
-            rhs = o["dmA"]                                                      # :233-236
+            rhs = o["dmA"]                                                                  # :233-236
         else:
-            curlcurl = o["curlE"] @ o["curlB"]
-            graddiv = o["gradPsi"] @ o["divB"]
-            scalapl = -(o["divB"] @ o["gradPsi"])
             rhs = sp.identity(len(self.B.gids), format="csr",
-                              dtype=complex if self.is_complex else float)     # :240-241
-        veclapl = purge_zeros((curlcurl - graddiv).tocsr())                     # :183-193
+                              dtype=complex if self.is_complex else float)                 # :240-241
+        veclapl = purge_zeros((curlcurl - graddiv).tocsr())                                 # :183-193
         for m in (curlcurl, graddiv, scalapl):
             m.sort_indices()
         o.update(curlCurl=curlcurl.tocsr(), gradDiv=graddiv.tocsr(), vecLapl=veclapl,

@@ -1,0 +1,79 @@
+"""K10: the inner Krylov solves (AztecOO replacement) against a direct solve of the same system."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import maxwell_amd as mx
+from oracle import yee
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(o, shift):
+    L, M = o["vecLapl"], o["mRhs"]
+    A = yee.shifted(L, M, shift)
+    used = M.diagonal() > 0
+    return A, used
+
+
+@pytest.mark.parametrize("method,precond", [("cg", "none"), ("cg", "jacobi"), ("gmres", "none"), ("gmres", "jacobi")])
+def test_shifted_veclapl_solve(ctx, oracle_pillbox12, rng, method, precond):
+    """(vecLapl - shift dmA) x = dmA b, the first solve of MxMagWaveOp::Apply
+    (src/MxMagWaveOp.cpp:865-885); unused rows are zero rows with zero right-hand side."""
+    _, o = oracle_pillbox12
+    A, used = _system(o, yee.default_shift([1, 1, 1]))
+    rhs = o["mRhs"] @ rng.uniform(-1, 1, A.shape[0])
+    assert np.all(rhs[~used] == 0)
+    dev = mx.CsrMatrix.from_scipy(ctx, A)
+    b = mx.MultiVec.from_numpy(ctx, rhs)
+    x = mx.MultiVec(ctx, A.shape[0], 1)
+    iters, conv, res = dev.solve(b, x, method=method, tol=1e-9, restart=40, precond=precond)
+    assert conv and res <= 1e-9
+    sol = x.to_numpy()[:, 0]
+    assert np.linalg.norm(A @ sol - rhs) <= 2e-9          # unscaled true residual (AZ_noscaled)
+    ref = np.zeros_like(sol)
+    ref[used] = spla.spsolve(A[used][:, used].tocsc(), rhs[used])
+    assert np.linalg.norm(sol - ref) <= 1e-7 * np.linalg.norm(ref)
+    assert np.all(sol[~used] == 0)
+
+
+def test_scalar_laplacian_solve_two_columns(ctx, oracle_pillbox12, rng):
+    """scaLapl psi = divB dmA b (second solve, :903-913): singular with the constant vector in the
+    null space; the right-hand side is in the range, CG converges to a solution."""
+    _, o = oracle_pillbox12
+    S = o["scaLapl"]
+    rhs = (o["divB"] @ (o["mRhs"] @ rng.uniform(-1, 1, (o["mRhs"].shape[0], 2))))
+    dev = mx.CsrMatrix.from_scipy(ctx, S)
+    b = mx.MultiVec.from_numpy(ctx, rhs)
+    x = mx.MultiVec(ctx, S.shape[0], 2)
+    iters, conv, res = dev.solve(b, x, method="cg", tol=1e-8)
+    assert conv
+    assert np.linalg.norm(S @ x.to_numpy() - rhs, axis=0).max() <= 2e-8
+
+
+def test_gmres_nonsymmetric_complex(ctx, rng):
+    """Config 5 flavour: non-Hermitian complex system (diagonally dominant)."""
+    n = 4000
+    R = sp.random(n, n, density=5.0 / n, random_state=3, format="csr")
+    A = (sp.diags(np.full(n, 8.0 + 1.0j)) + R + 0.5j * sp.random(n, n, density=3.0 / n, random_state=4, format="csr")).tocsr()
+    A.sort_indices()
+    rhs = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    dev = mx.CsrMatrix.from_scipy(ctx, A)
+    b = mx.MultiVec.from_numpy(ctx, rhs)
+    x = mx.MultiVec(ctx, n, 1, True)
+    iters, conv, res = dev.solve(b, x, method="gmres", tol=1e-10, restart=30)
+    assert conv
+    assert np.linalg.norm(A @ x.to_numpy()[:, 0] - rhs) <= 2e-10
+
+
+def test_unconverged_is_reported_not_spun(ctx, oracle_pillbox12, rng):
+    """The reference loops forever on an unconverged solve (src/MxMagWaveOp.cpp:876); here the
+    iteration cap returns converged = False."""
+    _, o = oracle_pillbox12
+    A, _ = _system(o, yee.default_shift([1, 1, 1]))
+    dev = mx.CsrMatrix.from_scipy(ctx, A)
+    b = mx.MultiVec.from_numpy(ctx, o["mRhs"] @ rng.uniform(-1, 1, A.shape[0]))
+    x = mx.MultiVec(ctx, A.shape[0], 1)
+    iters, conv, res = dev.solve(b, x, method="cg", tol=1e-14, max_iters=5)
+    assert not conv and iters <= 6 and res > 1e-14

@@ -1,0 +1,156 @@
+"""K1: CSR SpMV / SpMM through the C ABI against the serial row loop of the oracle -- bit exact
+(products are rounded, then added in storage order on both sides)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import maxwell_amd as mx
+from oracle import cref, yee
+
+pytestmark = pytest.mark.gpu
+
+
+def _apply(ctx, m, x):
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    X = mx.MultiVec.from_numpy(ctx, x)
+    Y = mx.MultiVec(ctx, m.shape[0], X.k, X.is_complex)
+    A.apply(X, Y)
+    return Y.to_numpy()
+
+
+@pytest.mark.parametrize("name", ["vecLapl", "scaLapl", "curlCurl", "gradDiv", "mRhs", "divB",
+                                  "gradPsi", "curlE", "curlB"])
+def test_pillbox_operators_bit_exact(ctx, oracle_pillbox16, rng, name):
+    """Every operator MxMagWaveOp applies (a2-a5 of SURVEY 8a), square and rectangular."""
+    _, o = oracle_pillbox16
+    m = o[name].tocsr()
+    x = rng.uniform(-1, 1, m.shape[1])
+    got = _apply(ctx, m, x)[:, 0]
+    assert np.array_equal(got, cref.spmv(m, x))
+
+
+def test_shifted_operator_from_product_assembler(ctx, oracle_pillbox16, rng):
+    """The matrix the hot loop really uses: vecLapl - shift*dmA built by the C++ assembler."""
+    _, o = oracle_pillbox16
+    shift = yee.default_shift([1, 1, 1])
+    sim = mx.Sim.pillbox(16)
+    host = sim.op("vecLapl", shift=shift)
+    ref = yee.shifted(o["vecLapl"], o["mRhs"], shift)
+    x = rng.uniform(-1, 1, host.shape[1])
+    A = sim.to_device(ctx, "vecLapl", shift=shift)
+    X = mx.MultiVec.from_numpy(ctx, x)
+    Y = mx.MultiVec(ctx, host.shape[0], 1)
+    A.apply(X, Y)
+    assert np.array_equal(Y.to_numpy()[:, 0], cref.spmv(ref, x))
+
+
+@pytest.mark.parametrize("k", [2, 3, 8])
+def test_spmm_block_of_vectors(ctx, oracle_pillbox12, rng, k):
+    _, o = oracle_pillbox12
+    m = o["curlCurl"]
+    x = rng.uniform(-1, 1, (m.shape[1], k))
+    assert np.array_equal(_apply(ctx, m, x), cref.spmv(m, x))
+
+
+def test_apply_in_place_aliasing(ctx, oracle_pillbox12, rng):
+    """apply(x, x) is used by the reference (src/MxMagWaveOp.cpp:650,1249)."""
+    _, o = oracle_pillbox12
+    m = o["vecLapl"]
+    x = rng.uniform(-1, 1, (m.shape[1], 2))
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    X = mx.MultiVec.from_numpy(ctx, x)
+    A.apply(X, X)
+    assert np.array_equal(X.to_numpy(), cref.spmv(m, x))
+    # partial overlap through views of one allocation
+    Z = mx.MultiVec.from_numpy(ctx, np.concatenate([x, x], axis=1))
+    A.apply(Z.view([0, 1]), Z.view([1, 2]))
+    want = cref.spmv(m, x)
+    got = Z.to_numpy()
+    assert np.array_equal(got[:, 1:3], want) and np.array_equal(got[:, 0], x[:, 0])
+
+
+def test_views_of_noncontiguous_columns(ctx, oracle_pillbox12, rng):
+    _, o = oracle_pillbox12
+    m = o["vecLapl"]
+    x = rng.uniform(-1, 1, (m.shape[1], 5))
+    X = mx.MultiVec.from_numpy(ctx, x)
+    Y = mx.MultiVec(ctx, m.shape[0], 5)
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    A.apply(X.view([4, 0, 2]), Y.view([1, 3, 0]))
+    got = Y.to_numpy()
+    want = cref.spmv(m, x[:, [4, 0, 2]])
+    assert np.array_equal(got[:, [1, 3, 0]], want) and np.all(got[:, [2, 4]] == 0)
+
+
+def test_complex_matrix(ctx, rng):
+    """Complex scalars are interleaved pairs (the reference's 2x2 real embedding,
+    src/MxCrsMatrix.cpp:146-170, collapses to complex multiply-add)."""
+    n = 3000
+    m = sp.random(n, n, density=4.0 / n, random_state=7, format="csr") \
+        + 1j * sp.random(n, n, density=4.0 / n, random_state=8, format="csr")
+    m = m.tocsr(); m.sort_indices()
+    x = rng.uniform(-1, 1, (n, 2)) + 1j * rng.uniform(-1, 1, (n, 2))
+    got = _apply(ctx, m, x)
+    assert np.array_equal(got, cref.spmv(m, x))
+
+
+def test_ragged_rows_empty_rows_and_long_row(ctx, rng):
+    """Edge cases: empty rows, rows longer than one row block (falls back to the whole-workgroup
+    path), more empty rows than a block can index, odd nnz offsets."""
+    n = 5000
+    rows = [rng.choice(n, size=int(c), replace=False) for c in rng.integers(0, 30, size=n)]
+    rows[17] = np.arange(n)[: 4500]            # > NNZ_BLK entries in one row
+    for r in range(100, 2400):                 # > ROWS_BLK consecutive empty rows
+        rows[r] = np.array([], dtype=int)
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    indices = np.concatenate([np.sort(r) for r in rows])
+    data = rng.uniform(-1, 1, len(indices))
+    m = sp.csr_matrix((data, indices, indptr), shape=(n, n))
+    x = rng.uniform(-1, 1, n)
+    got = _apply(ctx, m, x)[:, 0]
+    want = cref.spmv(m, x)
+    long_row = 17
+    mask = np.ones(n, bool); mask[long_row] = False
+    assert np.array_equal(got[mask], want[mask])
+    assert abs(got[long_row] - want[long_row]) <= 1e-12 * np.abs(data[indptr[17]:indptr[18]]).sum()
+
+
+def test_empty_and_tiny(ctx):
+    m = sp.csr_matrix((3, 3))
+    assert np.array_equal(_apply(ctx, m, np.ones(3))[:, 0], np.zeros(3))
+    m = sp.csr_matrix(np.array([[2.0]]))
+    assert _apply(ctx, m, np.array([3.0]))[0, 0] == 6.0
+
+
+def test_error_behaviour(ctx, oracle_pillbox12):
+    _, o = oracle_pillbox12
+    A = mx.CsrMatrix.from_scipy(ctx, o["divB"])
+    X = mx.MultiVec(ctx, o["divB"].shape[0], 1)      # wrong length on purpose
+    Y = mx.MultiVec(ctx, o["divB"].shape[0], 1)
+    with pytest.raises(mx.MxError, match="rows"):
+        A.apply(X, Y)
+    bad = o["divB"].copy().tocsr()
+    bad.indices = bad.indices.copy(); bad.indices[0] = bad.shape[1] + 5
+    with pytest.raises(mx.MxError, match="out of range"):
+        mx.CsrMatrix.from_scipy(ctx, bad)
+
+
+def test_full_size_linearity_and_constant_nullspace(ctx):
+    """Size-independent properties at a larger size (64^3 pillbox, ~3.4e5 rows):
+    linearity A(ax+by) = aAx + bAy to rounding, and divB*curlE = 0 applied as two SpMVs."""
+    sim = mx.Sim.pillbox(64)
+    rng = np.random.default_rng(1)
+    A = sim.to_device(ctx, "vecLapl", shift=1.97)
+    n = A.nrows
+    x = rng.uniform(-1, 1, n); y = rng.uniform(-1, 1, n)
+    X = mx.MultiVec.from_numpy(ctx, np.stack([x, y, 2.0 * x - 3.0 * y], axis=1))
+    Y = mx.MultiVec(ctx, n, 3)
+    A.apply(X, Y)
+    out = Y.to_numpy()
+    scale = np.abs(out).max()
+    assert np.abs(out[:, 2] - (2.0 * out[:, 0] - 3.0 * out[:, 1])).max() < 1e-12 * scale
+    curlE = sim.to_device(ctx, "curlE"); divB = sim.to_device(ctx, "divB")
+    e = mx.MultiVec.from_numpy(ctx, rng.uniform(-1, 1, curlE.ncols))
+    b = mx.MultiVec(ctx, curlE.nrows, 1); p = mx.MultiVec(ctx, divB.nrows, 1)
+    curlE.apply(e, b); divB.apply(b, p)
+    assert p.norm2()[0] < 1e-9 * b.norm2()[0]
