@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--n", type=int, default=256, help="Yee cells per side (per GPU)")
     p.add_argument("--k", type=int, default=1, help="vectors in the block (SpMM when > 1)")
-    p.add_argument("--kernel", type=int, default=0)
+    p.add_argument("--kernel", type=lambda v: int(v, 0), default=-1, help="SpMV kernel variant code (default: library default)")
     p.add_argument("--eig-n", type=int, default=96, help="grid of the eigenpairs/s measurement (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
     return p.parse_args()
@@ -73,6 +73,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("WARNING: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    from maxwell_amd import _env
+    _env.set_omp_threads()                     # the box's CPU share, not its 256 visible threads
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
@@ -105,7 +107,8 @@ def main():
         sim, A, workload, parallelism = mxd.bench_setup(ctx, args.n, shift)
     setup_s = time.perf_counter() - t0
     log("rank %d setup %.1f s: rows %d nnz %d" % (rank, setup_s, A.nrows, A.nnz))
-    A.set_kernel(args.kernel)
+    if args.kernel >= 0:
+        A.set_kernel(args.kernel)
 
     X = mx.MultiVec(ctx, A.ncols, args.k)
     Y = mx.MultiVec(ctx, A.nrows, args.k)
@@ -146,7 +149,7 @@ def main():
                    "setup_seconds": round(setup_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "k_spmv_stream<false>" if args.kernel == 0 else "k_spmv_vector<8>",
+                     "kernel": "k_spmv_rowgather<RgCfg<256,2048>,7>" if args.kernel < 0 else "variant %#x" % args.kernel,
                      "kernel_ms": round(kern_ms, 5),
                      "algorithmic_bytes_per_launch": alg // world,
                      "note": "achieved = nnz*12 + rows*(8+8k) + cols*8k bytes / HIP-event time per launch"},

@@ -90,7 +90,8 @@ int mxg_csr_apply(mxg_ctx* ctx, const mxg_csr* a, const mxg_mv* x, mxg_mv* y);
 /* algorithmic bytes of one apply with k columns (SURVEY section 8(d) formula):
  * nnz*(vb+4) + nrows*(8 + sb*k) + ncols*sb*k, vb = sb = 8 (real) or 16 (complex) */
 int64_t mxg_csr_apply_bytes(const mxg_csr* a, int k);
-/* tuning knob for experiments: 0 = stream kernel (default), 1 = row-per-lane-group kernel */
+/* tuning knob for experiments (scripts/tune_spmv.py): selects one of the SpMV kernel variants;
+ * the default (row-gather kernel) is set at creation and needs no call */
 int mxg_csr_set_kernel(mxg_csr* a, int which);
 
 /* ------------------------------------------------------------------------------------------

@@ -1,0 +1,22 @@
+"""Host thread budget: honour the container's CPU quota instead of the visible core count."""
+import os
+
+
+def host_threads(default_cap=64):
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) // int(period)))
+    except Exception:
+        pass
+    try:
+        return min(len(os.sched_getaffinity(0)), default_cap)
+    except Exception:
+        return min(os.cpu_count() or 1, default_cap)
+
+
+def set_omp_threads():
+    """Must run before libgomp is loaded (i.e. before libmxhost / liboracle are opened)."""
+    if "OMP_NUM_THREADS" not in os.environ:
+        os.environ["OMP_NUM_THREADS"] = str(host_threads())
+    return int(os.environ["OMP_NUM_THREADS"])

@@ -128,5 +128,7 @@ def load_mxg():
 
 
 def load_mxhost():
+    from . import _env
+    _env.set_omp_threads()
     load_mxg()
     return _load("libmxhost.so", MXH_SIGNATURES)

@@ -16,25 +16,37 @@
 //     its own slice of x (plus the stencil halo) instead of the whole vector;
 //   * k right-hand sides re-use the register-resident matrix entries of the block.
 #include <algorithm>
+#include <functional>
+#include <thread>
 
 #include "mxg_internal.h"
 
 namespace {
 
-constexpr int SBLK = 256;        // threads per workgroup
-constexpr int NNZ_BLK = 2048;    // non-zeros per row block (16 KiB of real products)
-constexpr int ROWS_BLK = 1024;   // rows per row block (bounded separately because of empty rows)
-constexpr int EPT = NNZ_BLK / SBLK;  // entries per thread
-// the real kernel loads aligned pairs starting at (base & ~1), so a block may hold at most
-// NNZ_BLK - 1 entries to stay inside the EPT * SBLK window
-constexpr int NNZ_CAP = NNZ_BLK - 1;
+// Launch geometry of the stream kernel: SBLK threads own a row block of at most
+// NNZ_BLK = SBLK * EPT non-zeros (8 bytes of LDS each) and ROWS_BLK rows (bounded separately
+// because of empty rows).  The real kernel loads aligned pairs starting at (base & ~1), so a
+// block holds at most NNZ_BLK - 1 entries to stay inside the EPT * SBLK window.
+template <int SBLK_, int EPT_>
+struct StreamCfg {
+  static constexpr int SBLK = SBLK_;
+  static constexpr int EPT = EPT_;
+  static constexpr int NNZ_BLK = SBLK_ * EPT_;
+  static constexpr int ROWS_BLK = NNZ_BLK / 2;
+  static constexpr int NNZ_CAP = NNZ_BLK - 1;
+};
+typedef StreamCfg<256, 8> CfgDefault;   // 2048 nnz, 16 KiB products + 4 KiB offsets per block
+typedef StreamCfg<512, 8> CfgWide;      // 4096 nnz, 512 threads
+typedef StreamCfg<256, 4> CfgSmall;     // 1024 nnz: more, lighter blocks
+typedef StreamCfg<256, 16> CfgTall;     // 4096 nnz, 256 threads, 16 entries per thread
+constexpr int SBLK = 256;               // block size of the auxiliary kernels
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int int2v __attribute__((ext_vector_type(2)));
 
-template <typename T>
+template <bool NT = true, typename T>
 __device__ inline T nt_load(const T* p) {
-  return __builtin_nontemporal_load(p);
+  return NT ? __builtin_nontemporal_load(p) : *p;
 }
 
 // XCD-aware remap of the hardware workgroup id to a logical row block:
@@ -46,23 +58,25 @@ __device__ inline long long xcd_block(long long w, long long nblocks) {
 }
 
 // One row block per workgroup.  CPLX: values and vectors are (re, im) pairs.
-template <bool CPLX>
-__global__ __launch_bounds__(SBLK) void k_spmv_stream(
+template <bool CPLX, typename CFG, bool NT, bool XCD, int DIAG = 0>
+__global__ __launch_bounds__(CFG::SBLK) void k_spmv_stream(
     const long long* __restrict__ rowptr, const int* __restrict__ colidx,
     const double* __restrict__ vals, const int* __restrict__ rowblk, long long nblocks,
     MvDesc X, MvDesc Y) {
   constexpr int W = CPLX ? 2 : 1;
+  constexpr int SBLK = CFG::SBLK, EPT = CFG::EPT, NNZ_BLK = CFG::NNZ_BLK, ROWS_BLK = CFG::ROWS_BLK,
+                NNZ_CAP = CFG::NNZ_CAP;
   __shared__ double prod[NNZ_BLK * W];
   __shared__ int off[ROWS_BLK + 1];
 
-  const long long b = xcd_block(blockIdx.x, nblocks);
+  const long long b = XCD ? xcd_block(blockIdx.x, nblocks) : (long long)blockIdx.x;
   if (b >= nblocks) return;
   const int r0 = rowblk[b], r1 = rowblk[b + 1];
   const int nr = r1 - r0;
   const long long base = rowptr[r0];
   const int nnzb = (int)(rowptr[r1] - base);
 
-  for (int t = threadIdx.x; t <= nr; t += SBLK) off[t] = (int)(nt_load(rowptr + r0 + t) - base);
+  for (int t = threadIdx.x; t <= nr; t += SBLK) off[t] = (int)(nt_load<NT>(rowptr + r0 + t) - base);
 
   if (nnzb <= NNZ_CAP) {
     // register-resident copy of this block's entries; pairs are loaded from an even
@@ -77,9 +91,9 @@ __global__ __launch_bounds__(SBLK) void k_spmv_stream(
         const long long idx = lo + threadIdx.x + (long long)e * SBLK;
         ok[e] = idx < base + nnzb;
         if (ok[e]) {
-          dbl2 vv = nt_load(reinterpret_cast<const dbl2*>(vals) + idx);
+          dbl2 vv = nt_load<NT>(reinterpret_cast<const dbl2*>(vals) + idx);
           v[e][0] = vv.x; v[e][W - 1] = vv.y;
-          c[e] = nt_load(colidx + idx);
+          c[e] = nt_load<NT>(colidx + idx);
         }
       }
     } else {
@@ -90,8 +104,8 @@ __global__ __launch_bounds__(SBLK) void k_spmv_stream(
         const bool in1 = idx + 1 < base + nnzb;   // idx + 1 >= base always holds
         ok[e] = in0; ok[e + 1] = in1;
         if (in0 || in1) {
-          dbl2 vv = nt_load(reinterpret_cast<const dbl2*>(vals + idx));
-          int2v cc = nt_load(reinterpret_cast<const int2v*>(colidx + idx));
+          dbl2 vv = nt_load<NT>(reinterpret_cast<const dbl2*>(vals + idx));
+          int2v cc = nt_load<NT>(reinterpret_cast<const int2v*>(colidx + idx));
           v[e][0] = vv.x; v[e + 1][0] = vv.y;
           c[e] = cc.x; c[e + 1] = cc.y;
         }
@@ -116,7 +130,11 @@ __global__ __launch_bounds__(SBLK) void k_spmv_stream(
         for (int e = 0; e < EPT; ++e) {
           if (ok[e]) {
             const int p = (int)(lo - base) + 2 * (threadIdx.x + (e / 2) * SBLK) + (e & 1);
-            prod[p] = v[e][0] * x[c[e]];
+            // DIAG builds are timing-only probes (wrong results): 1 = no x gather at all,
+            // 2 = gather from a 2 KiB window (always L1 resident)
+            if (DIAG == 1) prod[p] = v[e][0] * (double)c[e];
+            else if (DIAG == 2) prod[p] = v[e][0] * x[c[e] & 255];
+            else prod[p] = v[e][0] * x[c[e]];
           }
         }
       }
@@ -130,11 +148,13 @@ __global__ __launch_bounds__(SBLK) void k_spmv_stream(
             sr += pv.x; si += pv.y;
           }
           dbl2 out2; out2.x = sr; out2.y = si;
-          __builtin_nontemporal_store(out2, reinterpret_cast<dbl2*>(y) + r0 + t);
+          if (NT) __builtin_nontemporal_store(out2, reinterpret_cast<dbl2*>(y) + r0 + t);
+          else reinterpret_cast<dbl2*>(y)[r0 + t] = out2;
         } else {
           double sum = 0.0;
           for (int q = s; q < e; ++q) sum += prod[q];
-          __builtin_nontemporal_store(sum, y + r0 + t);
+          if (NT) __builtin_nontemporal_store(sum, y + r0 + t);
+          else y[r0 + t] = sum;
         }
       }
     }
@@ -171,6 +191,364 @@ __global__ __launch_bounds__(SBLK) void k_spmv_stream(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Software-pipelined persistent variant of the stream kernel (real scalars, one vector).
+// The one-block-per-workgroup kernel above has four dependent memory round trips per block
+// (block bounds -> row pointers / matrix stream -> x gather -> store), so even at full
+// occupancy a CU keeps too few bytes in flight to saturate HBM3E.  Here a workgroup walks a
+// strided sequence of row blocks and always has the NEXT block's matrix stream (values,
+// column indices, row pointers: registers only, no LDS) in flight while it gathers x,
+// reduces and stores the CURRENT block.  Block bounds come from one 32-byte descriptor.
+// Arithmetic and summation order are unchanged: results are bit-identical to the kernel above.
+// ------------------------------------------------------------------------------------------
+struct BlkDesc {
+  long long base;   // rowptr[r0]
+  int r0, nr, nnzb; // first row, rows, non-zeros of the block
+  int pad[3];
+};
+
+template <typename CFG>
+struct PipeRegs {
+  double v[CFG::EPT];
+  int c[CFG::EPT];
+  int o0[2], o1[2];   // row offsets (relative to base) of the <= 2 rows this thread sums
+};
+
+template <typename CFG>
+__device__ inline void pipe_load(PipeRegs<CFG>& R, const BlkDesc& d, const long long* __restrict__ rowptr,
+                                 const int* __restrict__ colidx, const double* __restrict__ vals) {
+  constexpr int SB = CFG::SBLK, EPT = CFG::EPT;
+  const long long lo = d.base & ~1LL;
+  const long long end = d.base + d.nnzb;
+#pragma unroll
+  for (int e = 0; e < EPT; e += 2) {
+    const long long idx = lo + 2 * (threadIdx.x + (long long)(e / 2) * SB);
+    if (idx < end) {   // pair (idx, idx+1) touches the block (idx + 1 >= base always)
+      dbl2 vv = nt_load(reinterpret_cast<const dbl2*>(vals + idx));
+      int2v cc = nt_load(reinterpret_cast<const int2v*>(colidx + idx));
+      R.v[e] = vv.x; R.v[e + 1] = vv.y;
+      R.c[e] = cc.x; R.c[e + 1] = cc.y;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int t = threadIdx.x + r * SB;
+    if (t < d.nr) {
+      R.o0[r] = (int)(nt_load(rowptr + d.r0 + t) - d.base);
+      R.o1[r] = (int)(nt_load(rowptr + d.r0 + t + 1) - d.base);
+    }
+  }
+}
+
+// issue the x gathers of a loaded block (its column indices are already in registers)
+template <typename CFG>
+__device__ inline void pipe_gather(const PipeRegs<CFG>& R, const BlkDesc& d, double (&xv)[CFG::EPT],
+                                   const double* __restrict__ x) {
+  constexpr int SB = CFG::SBLK, EPT = CFG::EPT;
+  const int shift = (int)((d.base & ~1LL) - d.base);   // 0 or -1
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int p = shift + 2 * (threadIdx.x + (e / 2) * SB) + (e & 1);
+    xv[e] = (p >= 0 && p < d.nnzb && d.nnzb <= CFG::NNZ_CAP) ? x[R.c[e]] : 0.0;
+  }
+}
+
+template <typename CFG>
+__device__ inline void pipe_finish(const PipeRegs<CFG>& R, const BlkDesc& d, const double (&xv)[CFG::EPT],
+                                   double* prod, const int* __restrict__ colidx,
+                                   const double* __restrict__ vals, const double* __restrict__ x,
+                                   double* __restrict__ y) {
+  constexpr int SB = CFG::SBLK, EPT = CFG::EPT;
+  if (d.nnzb <= CFG::NNZ_CAP) {
+    const int shift = (int)((d.base & ~1LL) - d.base);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int p = shift + 2 * (threadIdx.x + (e / 2) * SB) + (e & 1);
+      if (p >= 0 && p < d.nnzb) prod[p] = R.v[e] * xv[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int t = threadIdx.x + r * SB;
+      if (t < d.nr) {
+        double sum = 0.0;
+        for (int q = R.o0[r]; q < R.o1[r]; ++q) sum += prod[q];
+        __builtin_nontemporal_store(sum, y + d.r0 + t);
+      }
+    }
+    __syncthreads();
+  } else {
+    // single over-long row: whole workgroup strides over it, fixed-order combine
+    double sr = 0.0;
+    for (long long q = d.base + threadIdx.x; q < d.base + d.nnzb; q += SB) sr += vals[q] * x[colidx[q]];
+    prod[threadIdx.x] = sr;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tr = 0.0;
+      for (int q = 0; q < SB; ++q) tr += prod[q];
+      y[d.r0] = tr;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::SBLK) void k_spmv_pipe(
+    const BlkDesc* __restrict__ desc, long long nblocks, const long long* __restrict__ rowptr,
+    const int* __restrict__ colidx, const double* __restrict__ vals, const double* __restrict__ x,
+    double* __restrict__ y) {
+  __shared__ double prod[CFG::NNZ_BLK];
+  // XCD x walks its own contiguous eighth of the blocks; its workgroups interleave inside it
+  const long long per = (nblocks + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+  const long long xcd = blockIdx.x % MXG_NUM_XCD, slot = blockIdx.x / MXG_NUM_XCD;
+  const long long stride = gridDim.x / MXG_NUM_XCD;
+  long long b = xcd * per + slot;
+  long long last = (xcd + 1) * per;
+  if (last > nblocks) last = nblocks;
+  if (b >= last) return;
+  PipeRegs<CFG> A, B;
+  double xv[CFG::EPT];
+  BlkDesc dA = desc[b], dB;
+  pipe_load<CFG>(A, dA, rowptr, colidx, vals);
+  while (true) {
+    // the gathers of the current block are issued BEFORE the next block's stream: vmcnt retires
+    // in order, so the products below only wait for the gathers, not for the prefetch
+    pipe_gather<CFG>(A, dA, xv, x);
+    const bool moreB = b + stride < last;
+    if (moreB) { dB = desc[b + stride]; pipe_load<CFG>(B, dB, rowptr, colidx, vals); }
+    pipe_finish<CFG>(A, dA, xv, prod, colidx, vals, x, y);
+    if (!moreB) break;
+    b += stride;
+    pipe_gather<CFG>(B, dB, xv, x);
+    const bool moreA = b + stride < last;
+    if (moreA) { dA = desc[b + stride]; pipe_load<CFG>(A, dA, rowptr, colidx, vals); }
+    pipe_finish<CFG>(B, dB, xv, prod, colidx, vals, x, y);
+    if (!moreA) break;
+    b += stride;
+  }
+}
+
+typedef StreamCfg<256, 4> PipeCfgA;   // 1024 nnz per block, 8 KiB LDS
+typedef StreamCfg<256, 8> PipeCfgB;   // 2048 nnz per block, 16 KiB LDS
+
+
+// ------------------------------------------------------------------------------------------
+// x-window kernel (real scalars, one vector): the production SpMV.
+// Profiling the stream kernel showed the per-lane x gather through the vector L1 (one tag
+// lookup per touched 128-B line, ~12 lines per wave instruction) costs ~25 % of the run time
+// even when every line hits.  Here the x entries a row block needs are staged in LDS first:
+// at setup the block's column indices are clustered into <= 8 contiguous windows of x and
+// every non-zero gets a 16-bit LDS offset (window offset + col - window start).  The kernel
+// loads the windows with coalesced 16-byte loads, gathers from LDS, and never touches the
+// 32-bit column indices: the matrix stream shrinks from 12 to 10 bytes per non-zero.
+// Blocks whose columns do not cluster (more than 8 windows / more x entries than the LDS
+// tile) keep the global gather.  Products and the per-row summation order are unchanged, so
+// the result is still bit-identical to the serial CSR row loop.
+// ------------------------------------------------------------------------------------------
+constexpr int XW_MAXWIN = 8;
+struct BlkDescX {
+  long long base;            // rowptr[r0]
+  int r0, nr, nnzb, nwin;    // nwin < 0: unstaged block (global gather through colidx)
+  int win_lo[XW_MAXWIN];     // first x entry of each window (even)
+  int win_len[XW_MAXWIN];    // entries (even)
+  int pad[2];
+};
+static_assert(sizeof(BlkDescX) == 96, "descriptor layout");
+
+template <int SBLK_, int EPT_, int XCAP_>
+struct XwCfg {
+  static constexpr int SBLK = SBLK_, EPT = EPT_, XCAP = XCAP_;
+  static constexpr int NNZ_BLK = SBLK_ * EPT_;
+  static constexpr int NNZ_CAP = NNZ_BLK - 1;
+  static constexpr int ROWS_CAP = 2 * SBLK_;
+};
+typedef XwCfg<256, 8, 2048> XwCfgA;   // 16 KiB products + 16 KiB x tile
+typedef XwCfg<256, 4, 1024> XwCfgB;   //  8 KiB products +  8 KiB x tile
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::SBLK) void k_spmv_xwin(
+    const BlkDescX* __restrict__ desc, long long nblocks, const long long* __restrict__ rowptr,
+    const int* __restrict__ colidx, const unsigned short* __restrict__ lcol,
+    const double* __restrict__ vals, MvDesc X, MvDesc Y) {
+  constexpr int SB = CFG::SBLK, EPT = CFG::EPT;
+  __shared__ double prod[CFG::NNZ_BLK];
+  __shared__ double xs[CFG::XCAP];
+  const long long b = xcd_block(blockIdx.x, nblocks);
+  if (b >= nblocks) return;
+  const BlkDescX& d = desc[b];
+  const long long base = d.base;
+  const int r0 = d.r0, nr = d.nr, nnzb = d.nnzb, nwin = d.nwin;
+  if (nnzb > CFG::NNZ_CAP) {
+    // single over-long row: whole workgroup strides over it, fixed-order combine
+    for (int j = 0; j < X.k; ++j) {
+      const double* x = X.col(j);
+      double sr = 0.0;
+      for (long long q = base + threadIdx.x; q < base + nnzb; q += SB) sr += vals[q] * x[colidx[q]];
+      if (j > 0) __syncthreads();
+      prod[threadIdx.x] = sr;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double tr = 0.0;
+        for (int q = 0; q < SB; ++q) tr += prod[q];
+        Y.col(j)[r0] = tr;
+      }
+    }
+    return;
+  }
+  const long long lo = base & ~1LL;
+  const long long end = base + nnzb;
+  const int shift = (int)(lo - base);   // 0 or -1
+  // 1. matrix stream of the block -> registers (values + 16-bit local columns, or 32-bit columns)
+  double v[EPT];
+  int c[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; e += 2) {
+    const long long idx = lo + 2 * (threadIdx.x + (long long)(e / 2) * SB);
+    if (idx < end) {
+      dbl2 vv = nt_load(reinterpret_cast<const dbl2*>(vals + idx));
+      v[e] = vv.x; v[e + 1] = vv.y;
+      if (nwin >= 0) {
+        us2v cc = nt_load(reinterpret_cast<const us2v*>(lcol + idx));
+        c[e] = cc.x; c[e + 1] = cc.y;
+      } else {
+        int2v cc = nt_load(reinterpret_cast<const int2v*>(colidx + idx));
+        c[e] = cc.x; c[e + 1] = cc.y;
+      }
+    }
+  }
+  // row offsets of the (at most two) rows this thread sums
+  int o0[2], o1[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int t = threadIdx.x + r * SB;
+    if (t < nr) {
+      o0[r] = (int)(nt_load(rowptr + r0 + t) - base);
+      o1[r] = (int)(nt_load(rowptr + r0 + t + 1) - base);
+    }
+  }
+  for (int j = 0; j < X.k; ++j) {
+  const double* __restrict__ x = X.col(j);
+  double* __restrict__ y = Y.col(j);
+  if (j > 0) __syncthreads();   // previous column is done with prod[] / xs[]
+  // 2. x windows -> LDS (coalesced 16-byte loads; x stays cacheable, it is re-used by neighbours)
+  if (nwin > 0) {
+    int off = 0;
+    for (int w = 0; w < nwin; ++w) {
+      const int wlo = d.win_lo[w], wlen = d.win_len[w];
+      for (int i = 2 * threadIdx.x; i < wlen; i += 2 * SB)
+        *reinterpret_cast<double2*>(xs + off + i) = *reinterpret_cast<const double2*>(x + wlo + i);
+      off += wlen;
+    }
+    __syncthreads();
+  }
+  // 3. products
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int p = shift + 2 * (threadIdx.x + (e / 2) * SB) + (e & 1);
+    if (p >= 0 && p < nnzb) prod[p] = v[e] * (nwin >= 0 ? xs[c[e]] : x[c[e]]);
+  }
+  __syncthreads();
+  // 4. per-row sums in storage order
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int t = threadIdx.x + r * SB;
+    if (t < nr) {
+      double sum = 0.0;
+      for (int q = o0[r]; q < o1[r]; ++q) sum += prod[q];
+      __builtin_nontemporal_store(sum, y + r0 + t);
+    }
+  }
+  }  // columns
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Row-gather kernel (real scalars): coalesced matrix stream -> LDS (raw values + columns), then
+// ONE THREAD PER ROW walks its entries in LDS and gathers x.  Consecutive lanes hold consecutive
+// rows, whose k-th neighbours are consecutive x entries on the Yee lattice, so every gather
+// instruction touches a few contiguous 128-B lines instead of a dozen scattered ones (the
+// per-non-zero gather of the stream kernel costs ~25 % in L1 tag lookups even when it hits).
+// The row sum is formed in registers in storage order: bit-identical to the serial row loop.
+// ------------------------------------------------------------------------------------------
+template <int SBLK_, int NNZ_BLK_>
+struct RgCfg {
+  static constexpr int SBLK = SBLK_, NNZ_BLK = NNZ_BLK_;
+  static constexpr int NNZ_CAP = NNZ_BLK_ - 1;
+  static constexpr int ROWS_CAP = SBLK_;          // one row per thread
+  static constexpr int EPT = NNZ_BLK_ / SBLK_;
+};
+typedef RgCfg<256, 2048> RgCfgA;   // 16 KiB values + 8 KiB columns per block
+typedef RgCfg<256, 3072> RgCfgB;   // rows up to 12 nnz stay at 256 rows per block
+
+template <typename CFG, int CH>
+__global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
+    const BlkDesc* __restrict__ desc, long long nblocks, const long long* __restrict__ rowptr,
+    const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y) {
+  constexpr int SB = CFG::SBLK, EPT = CFG::EPT;
+  __shared__ double sval[CFG::NNZ_BLK];
+  __shared__ int scol[CFG::NNZ_BLK];
+  const long long b = xcd_block(blockIdx.x, nblocks);
+  if (b >= nblocks) return;
+  const BlkDesc d = desc[b];
+  if (d.nnzb > CFG::NNZ_CAP) {
+    for (int j = 0; j < X.k; ++j) {
+      const double* x = X.col(j);
+      double sr = 0.0;
+      for (long long q = d.base + threadIdx.x; q < d.base + d.nnzb; q += SB) sr += vals[q] * x[colidx[q]];
+      if (j > 0) __syncthreads();
+      sval[threadIdx.x] = sr;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double tr = 0.0;
+        for (int q = 0; q < SB; ++q) tr += sval[q];
+        Y.col(j)[d.r0] = tr;
+      }
+    }
+    return;
+  }
+  // coalesced stream -> LDS (aligned pairs from an even start, see the stream kernel)
+  const long long lo = d.base & ~1LL;
+  const long long end = d.base + d.nnzb;
+  const int shift = (int)(lo - d.base);
+#pragma unroll
+  for (int e = 0; e < EPT; e += 2) {
+    const long long idx = lo + 2 * (threadIdx.x + (long long)(e / 2) * SB);
+    if (idx < end) {
+      dbl2 vv = nt_load(reinterpret_cast<const dbl2*>(vals + idx));
+      int2v cc = nt_load(reinterpret_cast<const int2v*>(colidx + idx));
+      const int p = shift + 2 * (threadIdx.x + (e / 2) * SB);
+      if (p >= 0) { sval[p] = vv.x; scol[p] = cc.x; }
+      if (p + 1 < d.nnzb) { sval[p + 1] = vv.y; scol[p + 1] = cc.y; }
+    }
+  }
+  int o0 = 0, o1 = 0;
+  if ((int)threadIdx.x < d.nr) {
+    o0 = (int)(nt_load(rowptr + d.r0 + threadIdx.x) - d.base);
+    o1 = (int)(nt_load(rowptr + d.r0 + threadIdx.x + 1) - d.base);
+  }
+  __syncthreads();
+  for (int j = 0; j < X.k; ++j) {
+    const double* __restrict__ x = X.col(j);
+    double sum = 0.0;
+    for (int q0 = o0; q0 < o1; q0 += CH) {
+      double v[CH], xv[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const bool on = q0 + i < o1;
+        const int cc = on ? scol[q0 + i] : 0;
+        v[i] = on ? sval[q0 + i] : 0.0;
+        xv[i] = on ? x[cc] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+        if (q0 + i < o1) sum += v[i] * xv[i];
+    }
+    if ((int)threadIdx.x < d.nr) __builtin_nontemporal_store(sum, Y.col(j) + d.r0 + threadIdx.x);
+  }
+}
+
 // Reference-style kernel for A/B experiments: one row per group of G lanes, shuffle reduction.
 template <int G>
 __global__ __launch_bounds__(SBLK) void k_spmv_vector(
@@ -191,6 +569,22 @@ __global__ __launch_bounds__(SBLK) void k_spmv_vector(
     for (int o = G / 2; o > 0; o >>= 1) s += __shfl_down(s, o, G);
     if (row < nrows && sub == 0) y[row] = s;
   }
+}
+
+// greedy row blocks: <= nnz_cap non-zeros and <= rows_cap rows; an over-long row stands alone
+std::vector<int32_t> build_row_blocks(const int64_t* rowptr, int64_t nrows, int nnz_cap, int rows_cap) {
+  std::vector<int32_t> blk;
+  blk.push_back(0);
+  int64_t r = 0;
+  while (r < nrows) {
+    int64_t e = r;
+    const int64_t start = rowptr[r];
+    while (e < nrows && e - r < rows_cap && rowptr[e + 1] - start <= nnz_cap) ++e;
+    if (e == r) e = r + 1;  // single long row
+    blk.push_back((int32_t)e);
+    r = e;
+  }
+  return blk;
 }
 
 // pack x rows into the send buffer / copy owned part into the extended vector
@@ -215,7 +609,21 @@ __global__ void k_diag(const long long* __restrict__ rowptr, const int* __restri
   if (w == 2) diag[r * w + 1] = di;
 }
 
+template <bool CPLX, typename CFG, bool NT, bool XCD, int DIAG = 0>
+void launch_stream(mxg_ctx* c, const mxg_csr* a, const MvDesc& X, const MvDesc& Y) {
+  const long long per = (a->nblocks + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+  const unsigned grid = XCD ? (unsigned)(per * MXG_NUM_XCD) : (unsigned)a->nblocks;
+  hipLaunchKernelGGL((k_spmv_stream<CPLX, CFG, NT, XCD, DIAG>), dim3(grid), dim3(CFG::SBLK), 0, c->stream,
+                     (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, a->d_rowblk,
+                     (long long)a->nblocks, X, Y);
+}
+
 }  // namespace
+
+template <typename CFG>
+static int build_xwin(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx);
+static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr);
+constexpr int MXG_KERNEL_DEFAULT = 0x710000;
 
 extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, int64_t nghost,
                               const int64_t* rowptr, const int32_t* colidx, const double* vals,
@@ -242,18 +650,7 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
   a->is_complex = is_complex ? 1 : 0;
   const int w = is_complex ? 2 : 1;
 
-  // row blocks: greedy, <= NNZ_BLK non-zeros and <= ROWS_BLK rows; an over-long row stands alone
-  std::vector<int32_t> blk;
-  blk.push_back(0);
-  int64_t r = 0;
-  while (r < nrows) {
-    int64_t e = r;
-    const int64_t start = rowptr[r];
-    while (e < nrows && e - r < ROWS_BLK && rowptr[e + 1] - start <= NNZ_CAP) ++e;
-    if (e == r) e = r + 1;  // single long row
-    blk.push_back((int32_t)e);
-    r = e;
-  }
+  std::vector<int32_t> blk = build_row_blocks(rowptr, nrows, CfgDefault::NNZ_CAP, CfgDefault::ROWS_BLK);
   a->nblocks = (int64_t)blk.size() - 1;
 
   // +2 entries of slack: the real kernel loads aligned pairs and may touch one element past nnz
@@ -298,6 +695,12 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
                              hipMemcpyHostToDevice, c->stream));
   }
   MXG_HIP(hipStreamSynchronize(c->stream));
+  if (!a->is_complex && nnz > 0) {
+    // production kernel: row-gather, 2048-nnz blocks, gather chunk 7 (measured best on the
+    // 7-point bulk rows of the vector Laplacian; 70.8 % of HBM peak at 256^3)
+    MXG_TRY(build_pipe_desc(a, 10, rowptr));
+    a->kernel = MXG_KERNEL_DEFAULT;
+  }
   *out = a;
   return 0;
 }
@@ -308,6 +711,9 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   hipStreamSynchronize(a->ctx->stream);
   hipFree(a->d_rowptr); hipFree(a->d_colidx); hipFree(a->d_vals); hipFree(a->d_rowblk);
   hipFree(a->d_diag);
+  if (a->d_blkdesc) hipFree(a->d_blkdesc);
+  if (a->d_xwdesc) hipFree(a->d_xwdesc);
+  if (a->d_lcol) hipFree(a->d_lcol);
   if (a->d_send_idx) hipFree(a->d_send_idx);
   if (a->d_sendbuf) hipFree(a->d_sendbuf);
   if (a->d_xext) hipFree(a->d_xext);
@@ -330,8 +736,181 @@ extern "C" int64_t mxg_csr_apply_bytes(const mxg_csr* a, int k) {
   return a->nnz * (sb + 4) + a->nrows * (8 + sb * k) + (a->ncols_owned + a->nghost) * sb * k;
 }
 
+// row blocks depend on the block geometry: rebuild them from the device copy of rowptr
+static int rebuild_row_blocks(mxg_csr* a, int nnz_cap, int rows_cap) {
+  mxg_ctx* c = a->ctx;
+  std::vector<int64_t> rp(a->nrows + 1);
+  MXG_HIP(hipMemcpyAsync(rp.data(), a->d_rowptr, sizeof(int64_t) * (a->nrows + 1),
+                         hipMemcpyDeviceToHost, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  std::vector<int32_t> blk = build_row_blocks(rp.data(), a->nrows, nnz_cap, rows_cap);
+  hipFree(a->d_rowblk);
+  MXG_HIP(hipMalloc(&a->d_rowblk, sizeof(int32_t) * blk.size()));
+  MXG_HIP(hipMemcpyAsync(a->d_rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice,
+                         c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  a->nblocks = (int64_t)blk.size() - 1;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// setup of the x-window kernel: cluster every block's columns into windows, emit 16-bit
+// local column ids.  Runs on the host at matrix creation, spread over hardware threads.
+// ---------------------------------------------------------------------------------------
+template <typename CFG>
+static void build_xwin_range(const int64_t* rowptr, const int32_t* colidx, const std::vector<int32_t>& blk,
+                             size_t b0, size_t b1, BlkDescX* desc, unsigned short* lcol, int64_t* unstaged) {
+  constexpr int GAP = 64;   // start a new window when consecutive needed columns are further apart
+  std::vector<int32_t> u;
+  for (size_t b = b0; b < b1; ++b) {
+    BlkDescX d{};
+    d.r0 = blk[b]; d.nr = blk[b + 1] - blk[b];
+    d.base = rowptr[blk[b]];
+    d.nnzb = (int)(rowptr[blk[b + 1]] - d.base);
+    d.nwin = -1;
+    if (d.nnzb > 0 && d.nnzb <= CFG::NNZ_CAP) {
+      u.assign(colidx + d.base, colidx + d.base + d.nnzb);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      int nwin = 0, total = 0;
+      int lo[XW_MAXWIN], len[XW_MAXWIN], woff[XW_MAXWIN];
+      bool ok = true;
+      size_t i = 0;
+      while (i < u.size()) {
+        size_t j = i;
+        while (j + 1 < u.size() && u[j + 1] - u[j] <= GAP) ++j;
+        if (nwin == XW_MAXWIN) { ok = false; break; }
+        const int wlo = u[i] & ~1;
+        const int wlen = ((u[j] - wlo + 1) + 1) & ~1;
+        lo[nwin] = wlo; len[nwin] = wlen; woff[nwin] = total;
+        total += wlen;
+        ++nwin;
+        if (total > CFG::XCAP) { ok = false; break; }
+        i = j + 1;
+      }
+      if (ok) {
+        d.nwin = nwin;
+        for (int w = 0; w < nwin; ++w) { d.win_lo[w] = lo[w]; d.win_len[w] = len[w]; }
+        for (int64_t q = d.base; q < d.base + d.nnzb; ++q) {
+          const int32_t cc = colidx[q];
+          int w = 0;
+          while (w + 1 < nwin && cc >= lo[w + 1]) ++w;
+          lcol[q] = (unsigned short)(woff[w] + (cc - lo[w]));
+        }
+      } else {
+        *unstaged += 1;
+      }
+    } else if (d.nnzb == 0) {
+      d.nwin = 0;
+    }
+    desc[b] = d;
+  }
+}
+
+template <typename CFG>
+static int build_xwin(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx) {
+  mxg_ctx* c = a->ctx;
+  std::vector<int32_t> blk = build_row_blocks(rowptr, a->nrows, CFG::NNZ_CAP, CFG::ROWS_CAP);
+  const size_t nb = blk.size() - 1;
+  std::vector<BlkDescX> desc(std::max<size_t>(nb, 1));
+  std::vector<unsigned short> lcol((size_t)a->nnz + 2, 0);
+  unsigned nthreads = std::thread::hardware_concurrency();
+  if (nthreads > 16) nthreads = 16;
+  if (nthreads < 1) nthreads = 1;
+  if (nb < 64) nthreads = 1;
+  std::vector<int64_t> unstaged(nthreads, 0);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nthreads; ++t) {
+    const size_t b0 = nb * t / nthreads, b1 = nb * (t + 1) / nthreads;
+    pool.emplace_back(build_xwin_range<CFG>, rowptr, colidx, std::cref(blk), b0, b1, desc.data(),
+                      lcol.data(), &unstaged[t]);
+  }
+  for (auto& th : pool) th.join();
+  a->xw_unstaged = 0;
+  for (auto v : unstaged) a->xw_unstaged += v;
+  if (a->d_xwdesc) hipFree(a->d_xwdesc);
+  if (a->d_lcol) hipFree(a->d_lcol);
+  MXG_HIP(hipMalloc(&a->d_xwdesc, sizeof(BlkDescX) * desc.size()));
+  MXG_HIP(hipMalloc(&a->d_lcol, sizeof(unsigned short) * lcol.size()));
+  MXG_HIP(hipMemcpyAsync(a->d_xwdesc, desc.data(), sizeof(BlkDescX) * desc.size(), hipMemcpyHostToDevice,
+                         c->stream));
+  MXG_HIP(hipMemcpyAsync(a->d_lcol, lcol.data(), sizeof(unsigned short) * lcol.size(),
+                         hipMemcpyHostToDevice, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  a->nxw = (int64_t)nb;
+  return 0;
+}
+
+// descriptors of the pipelined kernel for block geometry `geo` (0: 256x4, 1: 256x8) and of the
+// row-gather kernel (10: 2048 nnz, 11: 3072 nnz, both 256 rows)
+static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
+  mxg_ctx* c = a->ctx;
+  std::vector<int64_t> rp_copy;
+  if (!host_rowptr) {
+    rp_copy.resize(a->nrows + 1);
+    MXG_HIP(hipMemcpyAsync(rp_copy.data(), a->d_rowptr, sizeof(int64_t) * (a->nrows + 1),
+                           hipMemcpyDeviceToHost, c->stream));
+    MXG_HIP(hipStreamSynchronize(c->stream));
+    host_rowptr = rp_copy.data();
+  }
+  int cap = geo == 0 ? PipeCfgA::NNZ_CAP : PipeCfgB::NNZ_CAP;
+  int rows_cap = 2 * (geo == 0 ? PipeCfgA::SBLK : PipeCfgB::SBLK);
+  if (geo == 10) { cap = RgCfgA::NNZ_CAP; rows_cap = RgCfgA::ROWS_CAP; }
+  if (geo == 11) { cap = RgCfgB::NNZ_CAP; rows_cap = RgCfgB::ROWS_CAP; }
+  std::vector<int32_t> blk = build_row_blocks(host_rowptr, a->nrows, cap, rows_cap);
+  std::vector<BlkDesc> desc(blk.size() - 1);
+  for (size_t b = 0; b + 1 < blk.size(); ++b) {
+    BlkDesc d{};
+    d.r0 = blk[b]; d.nr = blk[b + 1] - blk[b];
+    d.base = host_rowptr[blk[b]];
+    d.nnzb = (int)(host_rowptr[blk[b + 1]] - d.base);
+    desc[b] = d;
+  }
+  if (a->d_blkdesc) hipFree(a->d_blkdesc);
+  MXG_HIP(hipMalloc(&a->d_blkdesc, sizeof(BlkDesc) * std::max<size_t>(desc.size(), 1)));
+  if (!desc.empty())
+    MXG_HIP(hipMemcpyAsync(a->d_blkdesc, desc.data(), sizeof(BlkDesc) * desc.size(),
+                           hipMemcpyHostToDevice, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  a->npipe = (int64_t)desc.size();
+  a->pipe_geo = geo;
+  return 0;
+}
+
 extern "C" int mxg_csr_set_kernel(mxg_csr* a, int which) {
+  const int old_geo = (a->kernel >> 4) & 3, geo = (which >> 4) & 3;
   a->kernel = which;
+  if ((which & 0x30000) && !a->is_complex) {   // row-gather kernel: 0x10000 = 2048 nnz, 0x20000 = 3072 nnz
+    const int pg = (which & 0x20000) ? 11 : 10;
+    if (a->pipe_geo != pg) MXG_TRY(build_pipe_desc(a, pg, nullptr));
+    return 0;
+  }
+  if ((which & 0xC000) && !a->is_complex) {
+    const int xg = (which & 0x8000) ? 1 : 0;
+    if (a->xw_geo != xg) {
+      mxg_ctx* c = a->ctx;
+      std::vector<int64_t> rp(a->nrows + 1);
+      std::vector<int32_t> ci((size_t)a->nnz);
+      MXG_HIP(hipMemcpyAsync(rp.data(), a->d_rowptr, sizeof(int64_t) * (a->nrows + 1), hipMemcpyDeviceToHost, c->stream));
+      MXG_HIP(hipMemcpyAsync(ci.data(), a->d_colidx, sizeof(int32_t) * a->nnz, hipMemcpyDeviceToHost, c->stream));
+      MXG_HIP(hipStreamSynchronize(c->stream));
+      if (xg == 0) MXG_TRY(build_xwin<XwCfgA>(a, rp.data(), ci.data()));
+      else MXG_TRY(build_xwin<XwCfgB>(a, rp.data(), ci.data()));
+      a->xw_geo = xg;
+    }
+    return 0;
+  }
+  if ((which & 0xC0) && !a->is_complex) {
+    const int pg = (which & 0x80) ? 1 : 0;
+    if (a->pipe_geo != pg) MXG_TRY(build_pipe_desc(a, pg, nullptr));
+    return 0;
+  }
+  if (geo != old_geo && !a->is_complex) {
+    if (geo == 1) return rebuild_row_blocks(a, CfgWide::NNZ_CAP, CfgWide::ROWS_BLK);
+    if (geo == 2) return rebuild_row_blocks(a, CfgSmall::NNZ_CAP, CfgSmall::ROWS_BLK);
+    if (geo == 3) return rebuild_row_blocks(a, CfgTall::NNZ_CAP, CfgTall::ROWS_BLK);
+    return rebuild_row_blocks(a, CfgDefault::NNZ_CAP, CfgDefault::ROWS_BLK);
+  }
   return 0;
 }
 
@@ -412,22 +991,72 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
     }
   }
   if (a->nrows == 0) return 0;
-  if (a->kernel == 1 && !a->is_complex) {
+  (void)hipGetLastError();   // do not attribute a stale sticky error to this launch
+  if ((a->kernel & 0x30000) && !a->is_complex && a->npipe > 0) {
+    const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+    const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
+    const int ch = (a->kernel >> 20) & 0xF;   // gather chunk: 0 -> 8
+#define MXG_RG(CFG, CHV)                                                                           \
+    hipLaunchKernelGGL((k_spmv_rowgather<CFG, CHV>), dim3(grid), dim3(CFG::SBLK), 0, c->stream,       \
+                       (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr, \
+                       a->d_colidx, a->d_vals, X, Y)
+    if (a->pipe_geo == 10) { if (ch == 4) MXG_RG(RgCfgA, 4); else if (ch == 7) MXG_RG(RgCfgA, 7); else MXG_RG(RgCfgA, 8); }
+    else { if (ch == 4) MXG_RG(RgCfgB, 4); else if (ch == 7) MXG_RG(RgCfgB, 7); else MXG_RG(RgCfgB, 8); }
+#undef MXG_RG
+  } else if ((a->kernel & 0xC000) && !a->is_complex && a->nxw > 0) {
+    const long long per = (a->nxw + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+    const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
+    if (a->xw_geo == 0)
+      hipLaunchKernelGGL((k_spmv_xwin<XwCfgA>), dim3(grid), dim3(XwCfgA::SBLK), 0, c->stream,
+                         (const BlkDescX*)a->d_xwdesc, (long long)a->nxw, (const long long*)a->d_rowptr,
+                         a->d_colidx, a->d_lcol, a->d_vals, X, Y);
+    else
+      hipLaunchKernelGGL((k_spmv_xwin<XwCfgB>), dim3(grid), dim3(XwCfgB::SBLK), 0, c->stream,
+                         (const BlkDescX*)a->d_xwdesc, (long long)a->nxw, (const long long*)a->d_rowptr,
+                         a->d_colidx, a->d_lcol, a->d_vals, X, Y);
+  } else if ((a->kernel & 0xC0) && !a->is_complex && X.k == 1 && a->npipe > 0) {
+    int bpc = (a->kernel >> 8) & 0xF;
+    if (bpc == 0) bpc = 8;
+    long long grid = (long long)c->num_cu * bpc;
+    grid = (grid / MXG_NUM_XCD) * MXG_NUM_XCD;
+    if (grid < MXG_NUM_XCD) grid = MXG_NUM_XCD;
+    const double* xp = X.col(0);
+    double* yp = Y.col(0);
+    if (a->pipe_geo == 0)
+      hipLaunchKernelGGL((k_spmv_pipe<PipeCfgA>), dim3((unsigned)grid), dim3(PipeCfgA::SBLK), 0, c->stream,
+                         (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr,
+                         a->d_colidx, a->d_vals, xp, yp);
+    else
+      hipLaunchKernelGGL((k_spmv_pipe<PipeCfgB>), dim3((unsigned)grid), dim3(PipeCfgB::SBLK), 0, c->stream,
+                         (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr,
+                         a->d_colidx, a->d_vals, xp, yp);
+  } else if ((a->kernel & 1) && !a->is_complex) {
     const long long threads = (long long)a->nrows * 8;
     hipLaunchKernelGGL((k_spmv_vector<8>), dim3((unsigned)((threads + SBLK - 1) / SBLK)), dim3(SBLK),
                        0, c->stream, (const long long*)a->d_rowptr, a->d_colidx, a->d_vals,
                        (long long)a->nrows, X, Y);
+  } else if (a->is_complex) {
+    launch_stream<true, CfgDefault, true, true>(c, a, X, Y);
+  } else if (a->kernel & 0x3000) {
+    if ((a->kernel & 0x3000) == 0x1000) launch_stream<false, CfgDefault, true, true, 1>(c, a, X, Y);
+    else launch_stream<false, CfgDefault, true, true, 2>(c, a, X, Y);
   } else {
-    const long long per = (a->nblocks + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
-    const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
-    if (a->is_complex)
-      hipLaunchKernelGGL((k_spmv_stream<true>), dim3(grid), dim3(SBLK), 0, c->stream,
-                         (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, a->d_rowblk,
-                         (long long)a->nblocks, X, Y);
-    else
-      hipLaunchKernelGGL((k_spmv_stream<false>), dim3(grid), dim3(SBLK), 0, c->stream,
-                         (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, a->d_rowblk,
-                         (long long)a->nblocks, X, Y);
+    // tuning variants (mxg_csr_set_kernel): bit 1 = plain loads, bit 2 = no XCD remap,
+    // bits 4-5 = block geometry
+    const bool nt = !(a->kernel & 2), xcd = !(a->kernel & 4);
+    const int geo = (a->kernel >> 4) & 3;
+#define MXG_LAUNCH(CFG)                                                        \
+    do {                                                                       \
+      if (nt && xcd) launch_stream<false, CFG, true, true>(c, a, X, Y);        \
+      else if (nt) launch_stream<false, CFG, true, false>(c, a, X, Y);         \
+      else if (xcd) launch_stream<false, CFG, false, true>(c, a, X, Y);        \
+      else launch_stream<false, CFG, false, false>(c, a, X, Y);                \
+    } while (0)
+    if (geo == 1) MXG_LAUNCH(CfgWide);
+    else if (geo == 2) MXG_LAUNCH(CfgSmall);
+    else if (geo == 3) MXG_LAUNCH(CfgTall);
+    else MXG_LAUNCH(CfgDefault);
+#undef MXG_LAUNCH
   }
   MXG_HIP(hipGetLastError());
   return 0;

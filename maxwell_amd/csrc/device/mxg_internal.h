@@ -121,6 +121,16 @@ struct mxg_csr {
   int32_t* d_rowblk = nullptr;
   int64_t nblocks = 0;
   int kernel = 0;
+  // pipelined kernel: 32-byte block descriptors (built for the active geometry)
+  void* d_blkdesc = nullptr;
+  int64_t npipe = 0;
+  int pipe_geo = -1;
+  // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
+  void* d_xwdesc = nullptr;
+  unsigned short* d_lcol = nullptr;
+  int64_t nxw = 0;
+  int64_t xw_unstaged = 0;
+  int xw_geo = -1;
   // diagonal (for Jacobi) extracted at creation
   double* d_diag = nullptr;
   // halo

@@ -1,0 +1,7 @@
+set -x
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_spmv_gpu.py -m gpu -x -q > gpurun_out/pytest_spmv.log 2>&1
+rc=$?; tail -5 gpurun_out/pytest_spmv.log
+if [ $rc -ge 124 ]; then exit $rc; fi
+timeout -k 10 600 python scripts/tune_spmv.py 256 0x0,0x20,0x540,0x440,0x840,0x480,0x380,0x280 > gpurun_out/tune256b.txt 2>&1
+rc=$?; cat gpurun_out/tune256b.txt | tail -12

@@ -154,3 +154,46 @@ def test_full_size_linearity_and_constant_nullspace(ctx):
     b = mx.MultiVec(ctx, curlE.nrows, 1); p = mx.MultiVec(ctx, divB.nrows, 1)
     curlE.apply(e, b); divB.apply(b, p)
     assert p.norm2()[0] < 1e-9 * b.norm2()[0]
+
+
+@pytest.mark.parametrize("code", [0x10000, 0x20000, 0x710000, 0x410000, 0x4000, 0x8000, 0x0, 0x2, 0x4, 0x10, 0x20, 0x30, 0x540, 0x840, 0x480, 0x180, 0x1])
+def test_every_kernel_variant_bit_exact(ctx, oracle_pillbox16, rng, code):
+    """All tuning variants (plain / non-temporal loads, XCD remap, block geometries, the
+    software-pipelined persistent kernel) must give the same bits as the serial row loop;
+    the lane-group kernel (code 1) reduces with shuffles and is only rounding-close."""
+    _, o = oracle_pillbox16
+    m = yee.shifted(o["vecLapl"], o["mRhs"], 1.9739208802178716)
+    x = rng.uniform(-1, 1, m.shape[1])
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    A.set_kernel(code)
+    X = mx.MultiVec.from_numpy(ctx, x)
+    Y = mx.MultiVec(ctx, m.shape[0], 1)
+    A.apply(X, Y)
+    got, want = Y.to_numpy()[:, 0], cref.spmv(m, x)
+    if code == 1:
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    else:
+        assert np.array_equal(got, want)
+
+
+def test_pipelined_kernel_ragged(ctx, rng):
+    """Pipelined kernel on ragged rows incl. empty stretches and an over-long row."""
+    n = 6000
+    rows = [rng.choice(n, size=int(c), replace=False) for c in rng.integers(0, 25, size=n)]
+    rows[3] = np.arange(n)[:3000]
+    for r in range(500, 1700):
+        rows[r] = np.array([], dtype=int)
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    indices = np.concatenate([np.sort(r) for r in rows])
+    m = sp.csr_matrix((rng.uniform(-1, 1, len(indices)), indices, indptr), shape=(n, n))
+    x = rng.uniform(-1, 1, n)
+    want = cref.spmv(m, x)
+    for code in (0x10000, 0x20000, 0x4000, 0x8000, 0x540, 0x480):
+        A = mx.CsrMatrix.from_scipy(ctx, m)
+        A.set_kernel(code)
+        X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, n, 1)
+        A.apply(X, Y)
+        got = Y.to_numpy()[:, 0]
+        mask = np.ones(n, bool); mask[3] = False
+        assert np.array_equal(got[mask], want[mask])
+        assert abs(got[3] - want[3]) <= 1e-12 * np.abs(m[3].data).sum()
