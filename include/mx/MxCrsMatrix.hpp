@@ -1,0 +1,192 @@
+// Sparse matrix with the reference's interface (src/MxCrsMatrix.hpp:11-104).  Rows are collected
+// on the host (insertRowValues), fillComplete() freezes them into CSR and uploads to the GPU;
+// apply() is the HIP SpMV / SpMM of mxg_csr_apply.
+#ifndef MX_CRS_MATRIX
+#define MX_CRS_MATRIX
+
+#include <fstream>
+
+#include "MxVector.hpp"
+#include "mx_sparse.hpp"
+
+template <typename Scalar>
+class MxCrsMatrix {
+ public:
+  explicit MxCrsMatrix(RCP<MxMap> rowMap) : mFilled(false), mRowMap(rowMap), mColMap(rowMap), mDev(nullptr) { initRows(); }
+  MxCrsMatrix(RCP<MxMap> rowMap, RCP<MxMap> colMap) : mFilled(false), mRowMap(rowMap), mColMap(colMap), mDev(nullptr) { initRows(); }
+  // diagonal matrix from a scalar (src/MxCrsMatrix.cpp:33-47)
+  MxCrsMatrix(RCP<MxMap> rowMap, Scalar diag) : mFilled(false), mRowMap(rowMap), mColMap(rowMap), mDev(nullptr) {
+    initRows();
+    for (size_t i = 0; i < rowMap->getNodeNumIndices(); ++i) {
+      MxIndex g = rowMap->getGlobalIndex(i);
+      insertRowValues(g, 1, &g, &diag);
+    }
+    fillComplete(rowMap, rowMap);
+  }
+  // diagonal matrix from a vector (src/MxCrsMatrix.cpp:50-66)
+  explicit MxCrsMatrix(RCP<MxVector<Scalar> > diag) : mFilled(false), mRowMap(diag->getMap()), mColMap(diag->getMap()), mDev(nullptr) {
+    initRows();
+    std::vector<Scalar> d;
+    diag->getColumn(0, d);
+    for (size_t i = 0; i < d.size(); ++i) {
+      MxIndex g = mRowMap->getGlobalIndex(i);
+      insertRowValues(g, 1, &g, &d[i]);
+    }
+    fillComplete(mRowMap, mRowMap);
+  }
+  // adopt a finished local CSR (the fast path MxEMOps uses)
+  MxCrsMatrix(RCP<MxMap> rowMap, RCP<MxMap> colMap, mx::Csr<Scalar> const& csr)
+      : mFilled(false), mRowMap(rowMap), mColMap(colMap), mDev(nullptr) { adopt(csr); }
+
+  ~MxCrsMatrix() { if (mDev) mxg_csr_destroy(mDev); }
+
+  // indices are always global here
+  void insertRowValues(MxIndex row, std::vector<MxIndex> cols, std::vector<Scalar> vals) {
+    insertRowValues(row, cols.size(), cols.data(), vals.data());
+  }
+  void insertRowValues(MxIndex row, size_t numEntries, MxIndex const* cols, Scalar const* vals) {
+    if (mFilled) { std::cout << "MxCrsMatrix::insertRowValues: matrix already filled\n"; throw 1; }
+    const MxIndex lr = mRowMap->getLocalIndex(row);
+    if (lr == MxIndex(-1)) {
+      std::cout << "MxCrsMatrix::insertRowValues: row=" << row << " is not on this rank. numEntries=" << numEntries << "\n";
+      throw 1;
+    }
+    for (size_t i = 0; i < numEntries; ++i) mRows[lr].push_back(std::make_pair(cols[i], vals[i]));
+  }
+
+  void fillComplete(RCP<MxMap> domainMap, RCP<MxMap> rangeMap) {
+    mColMap = domainMap;
+    (void)rangeMap;
+    mx::Csr<Scalar> m;
+    m.nrows = (int64_t)mRowMap->getNodeNumIndices();
+    m.ncols = (int64_t)domainMap->getNodeNumIndices();
+    m.rowptr.resize(m.nrows + 1);
+    m.rowptr[0] = 0;
+    std::vector<std::pair<int32_t, Scalar> > row;
+    std::vector<int32_t> col; std::vector<Scalar> val;
+    for (int64_t r = 0; r < m.nrows; ++r) {
+      row.clear();
+      for (auto& e : mRows[r]) {
+        const MxIndex lc = domainMap->getLocalIndex(e.first);
+        if (lc == MxIndex(-1)) { std::cout << "MxCrsMatrix::fillComplete: column " << e.first << " not in the domain map\n"; throw 1; }
+        row.push_back(std::make_pair((int32_t)lc, e.second));
+      }
+      std::stable_sort(row.begin(), row.end(), [](const std::pair<int32_t, Scalar>& a, const std::pair<int32_t, Scalar>& b) { return a.first < b.first; });
+      for (size_t i = 0; i < row.size(); ++i) {   // repeated (row, col) inserts are summed, like Epetra
+        if (!col.empty() && (int64_t)col.size() > m.rowptr[r] && col.back() == row[i].first) val.back() += row[i].second;
+        else { col.push_back(row[i].first); val.push_back(row[i].second); }
+      }
+      m.rowptr[r + 1] = (int64_t)col.size();
+    }
+    m.col.assign(col.begin(), col.end());
+    m.val.assign(val.begin(), val.end());
+    mRows.clear();
+    adopt(m);
+  }
+
+  void scale(Scalar val) { mx::scaleInPlace(mHost, val); upload(); }
+  void leftScale(RCP<MxVector<Scalar> > vec) {
+    std::vector<Scalar> d;
+    vec->getColumn(0, d);
+    mx::UVec<Scalar> dd(d.begin(), d.end());
+    for (int64_t i = 0; i < mHost.nrows; ++i)
+      for (int64_t p = mHost.rowptr[i]; p < mHost.rowptr[i + 1]; ++p) mHost.val[p] *= dd[i];
+    upload();
+  }
+  void getLocalRow(MxIndex localRowIndex, std::vector<MxIndex>& localColIndices, std::vector<Scalar>& vals) const {
+    localColIndices.clear(); vals.clear();
+    for (int64_t p = mHost.rowptr[localRowIndex]; p < mHost.rowptr[localRowIndex + 1]; ++p) {
+      localColIndices.push_back((MxIndex)mHost.col[p]);
+      vals.push_back(mHost.val[p]);
+    }
+  }
+  RCP<MxVector<Scalar> > getRowSums(bool inverse) const {
+    RCP<MxVector<Scalar> > res = rcp(new MxVector<Scalar>(mRowMap));
+    std::vector<Scalar> s(mHost.nrows);
+    for (int64_t i = 0; i < mHost.nrows; ++i) {
+      Scalar sum = Scalar(0);   // the reference never resets `sum` (src/MxCrsMatrix.cpp:306-311)
+      for (int64_t p = mHost.rowptr[i]; p < mHost.rowptr[i + 1]; ++p) sum += mHost.val[p];
+      s[i] = inverse ? Scalar(1.0) / sum : sum;
+    }
+    res->setColumn(0, s);
+    return res;
+  }
+
+  // y = A x on the GPU; x may alias y (src/MxMagWaveOp.cpp:650,1249)
+  void apply(MxMultiVector<Scalar> const& x, MxMultiVector<Scalar>& y) const {
+    if (!mFilled) { std::cout << "MxCrsMatrix::apply: matrix is not fill-completed\n"; throw 1; }
+    ensureDevice();
+    MX_ABI(mxg_csr_apply(mRowMap->getComm()->getCtx(), mDev, x.raw(), y.raw()), "MxCrsMatrix::apply");
+  }
+
+  // MatrixMarket coordinate file <name>.mm (EpetraExt::RowMatrixToMatrixMarketFile)
+  void save(std::string name) const {
+    std::ofstream f((name + ".mm").c_str());
+    f.precision(17);
+    f << "%%MatrixMarket matrix coordinate " << (ScalarTraits<Scalar>::isComplex ? "complex" : "real") << " general\n";
+    f << mRowMap->getGlobalNumIndices() << " " << mColMap->getGlobalNumIndices() << " " << mHost.nnz() << "\n";
+    for (int64_t i = 0; i < mHost.nrows; ++i)
+      for (int64_t p = mHost.rowptr[i]; p < mHost.rowptr[i + 1]; ++p) {
+        f << mRowMap->getGlobalIndex(i) + 1 << " " << mColMap->getGlobalIndex(mHost.col[p]) + 1 << " " << mxRe(mHost.val[p]);
+        if (ScalarTraits<Scalar>::isComplex) f << " " << mxIm(mHost.val[p]);
+        f << "\n";
+      }
+  }
+
+  void purgeZeros() { mx::Csr<Scalar> p = mx::purge(mHost); adopt(p); }   // |a| > 1e-12 kept
+
+  void fillComplete() { fillComplete(mColMap, mRowMap); }
+  bool isFilled() const { return mFilled; }
+  RCP<MxMap> getDomainMap() const { return mColMap; }
+  RCP<MxMap> getRangeMap() const { return mRowMap; }
+
+  static void matrixMatrixMultiply(MxCrsMatrix<Scalar> const& a, bool transA, MxCrsMatrix<Scalar> const& b,
+                                   bool transB, MxCrsMatrix<Scalar>& result, bool fc) {
+    mx::Csr<Scalar> ta, tb;
+    const mx::Csr<Scalar>& A = transA ? (ta = mx::transpose(a.mHost, true)) : a.mHost;
+    const mx::Csr<Scalar>& B = transB ? (tb = mx::transpose(b.mHost, true)) : b.mHost;
+    result.mRowMap = transA ? a.mColMap : a.mRowMap;
+    result.mColMap = transB ? b.mRowMap : b.mColMap;
+    mx::Csr<Scalar> c = mx::multiply(A, B);
+    (void)fc;
+    result.adopt(c);
+  }
+  static void matrixMatrixAdd(MxCrsMatrix<Scalar> const& a, bool transA, Scalar scalarA,
+                              MxCrsMatrix<Scalar> const& b, bool transB, Scalar scalarB,
+                              MxCrsMatrix<Scalar>& result, bool fc) {
+    mx::Csr<Scalar> ta, tb;
+    const mx::Csr<Scalar>& A = transA ? (ta = mx::transpose(a.mHost, true)) : a.mHost;
+    const mx::Csr<Scalar>& B = transB ? (tb = mx::transpose(b.mHost, true)) : b.mHost;
+    result.mRowMap = transA ? a.mColMap : a.mRowMap;
+    result.mColMap = transA ? a.mRowMap : a.mColMap;
+    mx::Csr<Scalar> c = mx::add(A, scalarA, B, scalarB);
+    (void)fc;
+    result.adopt(c);
+  }
+
+  // host-side CSR (setup algebra, tests) and device handle (advanced usage)
+  mx::Csr<Scalar> const& getHostCsr() const { return mHost; }
+  mxg_csr* getRawMatrix() const { ensureDevice(); return mDev; }
+
+ private:
+  void initRows() { mRows.resize(mRowMap->getNodeNumIndices()); }
+  // the device copy is created on first use: setup-only intermediates never reach the GPU
+  void adopt(mx::Csr<Scalar> const& m) { mHost = m; upload(); }
+  void upload() {
+    if (mDev) { mxg_csr_destroy(mDev); mDev = nullptr; }
+    mFilled = true;
+  }
+  void ensureDevice() const {
+    if (mDev) return;
+    MX_ABI(mxg_csr_create(mRowMap->getComm()->getCtx(), mHost.nrows, mHost.ncols, 0, mHost.rowptr.data(),
+                          mHost.col.data(), reinterpret_cast<const double*>(mHost.val.data()),
+                          ScalarTraits<Scalar>::isComplex, NULL, &mDev), "MxCrsMatrix::fillComplete");
+  }
+  bool mFilled;
+  RCP<MxMap> mRowMap, mColMap;
+  std::vector<std::vector<std::pair<MxIndex, Scalar> > > mRows;
+  mx::Csr<Scalar> mHost;
+  mutable mxg_csr* mDev;
+};
+
+#endif

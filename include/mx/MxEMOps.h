@@ -1,0 +1,84 @@
+// name -> operator registry (reference src/MxEMOps.h:20-113, src/MxEMOps.cpp:39-268).
+#ifndef MX_EM_OPS
+#define MX_EM_OPS
+
+#include "MxCrsMatrix.hpp"
+#include "MxEMSim.h"
+
+template <size_t DIM, typename Scalar>
+class MxEMOps {
+ public:
+  explicit MxEMOps(RCP<MxEMSim<DIM> > sim, bool initSingleOps = true) : pid(sim->getGrid().getComm()->myPID()), mSim(sim) {
+    if (initSingleOps) setSingleOps();
+  }
+  // primitive operators straight from the assembler (src/MxEMOps.cpp:39-168)
+  void setSingleOps() {
+    const mx::YeeAssembler<double>& a = mSim->getAssembler();
+    RCP<MxMap> b = mSim->getField("bfield").getMap(), e = mSim->getField("efield").getMap(),
+               p = mSim->getField("psifield").getMap();
+    insert("curlE", b, e, a.curlE());
+    insert("curlB", e, b, a.curlB());
+    if (mSim->hasPEC()) {
+      insert("dmA", b, b, a.fracs(a.bfield(), false));
+      insert("dmL", e, e, a.fracs(a.efield(), false));
+    }
+    insert("divB", p, b, a.divB());
+    insert("gradPsi", b, p, a.gradPsi());
+    if (mSim->hasPEC()) insert("dmVInv", p, p, a.fracs(a.psifield(), true));
+  }
+  RCP<MxCrsMatrix<Scalar> > getOp(std::string name) const {
+    auto it = mOps.find(name);
+    if (it == mOps.end()) { std::cout << "MxEMOps::getOp: operator '" << name << "' not found.\n"; exit(EXIT_FAILURE); }
+    return it->second;
+  }
+  // product of the named operators, FIRST NAME APPLIED FIRST (src/MxEMOps.h:61-74):
+  // result = names[n-1] * ... * names[1] * names[0]  (massiveCrsMultiply, src/MxUtil.cpp:318-371)
+  RCP<MxCrsMatrix<Scalar> > multiplyOps(std::vector<std::string> const& names, std::vector<bool> const& transposes,
+                                         bool fillComplete, bool store = false, std::string name = "") {
+    RCP<MxCrsMatrix<Scalar> > m1 = getOp(names[0]);
+    bool t1 = transposes[0];
+    if (names.size() == 1) return m1;
+    RCP<MxCrsMatrix<Scalar> > res;
+    for (size_t i = 1; i < names.size(); ++i) {
+      RCP<MxCrsMatrix<Scalar> > m2 = getOp(names[i]);
+      res = rcp(new MxCrsMatrix<Scalar>(transposes[i] ? m2->getDomainMap() : m2->getRangeMap()));
+      MxCrsMatrix<Scalar>::matrixMatrixMultiply(*m2, transposes[i], *m1, t1, *res, fillComplete);
+      m1 = res;
+      t1 = false;
+    }
+    if (store) mOps[name] = res;
+    return res;
+  }
+  RCP<MxCrsMatrix<Scalar> > addOps(std::vector<std::string> const& names, std::vector<Scalar> const& scalars,
+                                    bool store = false, std::string name = "") {
+    RCP<MxCrsMatrix<Scalar> > acc = getOp(names[0]);
+    Scalar sa = scalars[0];
+    RCP<MxCrsMatrix<Scalar> > res;
+    for (size_t i = 1; i < names.size(); ++i) {
+      RCP<MxCrsMatrix<Scalar> > b = getOp(names[i]);
+      res = rcp(new MxCrsMatrix<Scalar>(acc->getRangeMap()));
+      MxCrsMatrix<Scalar>::matrixMatrixAdd(*acc, false, sa, *b, false, scalars[i], *res, true);
+      acc = res;
+      sa = ScalarTraits<Scalar>::one();
+    }
+    if (store) mOps[name] = res;
+    return res;
+  }
+  void saveOps() const { for (auto& e : mOps) e.second->save("Mx" + e.first); }
+ private:
+  void insert(const char* name, RCP<MxMap> rows, RCP<MxMap> cols, mx::Csr<double> const& m) {
+    mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, convert(m)));
+  }
+  static mx::Csr<Scalar> convert(mx::Csr<double> const& m) {
+    mx::Csr<Scalar> c;
+    c.nrows = m.nrows; c.ncols = m.ncols; c.rowptr = m.rowptr; c.col = m.col;
+    c.val.resize(m.val.size());
+    for (size_t i = 0; i < m.val.size(); ++i) c.val[i] = Scalar(m.val[i]);
+    return c;
+  }
+  int pid;
+  RCP<MxEMSim<DIM> > mSim;
+  std::map<std::string, RCP<MxCrsMatrix<Scalar> > > mOps;
+};
+
+#endif

@@ -1,0 +1,86 @@
+// Simulation container: grid + boundary conditions + PEC shape + parameter list, and the field
+// maps built from them.  Light-weight counterpart of MxEMSim / MxGrid / MxGridField
+// (reference src/MxEMSim.cpp:54-225, src/MxGridField.cpp:256-297): the geometry work is done by
+// the Yee assembler, this class exposes what MxSolver / MxMagWaveOp ask for.
+#ifndef MX_EM_SIM
+#define MX_EM_SIM
+
+#include "MxMap.hpp"
+#include "MxMultiVector.hpp"
+#include "mx_yee.hpp"   // maxwell_amd/csrc/host (on the include path of the host library)
+
+template <size_t DIM> class MxEMSim;
+
+template <size_t DIM>
+class MxGrid {
+ public:
+  explicit MxGrid(RCP<MxComm> comm) : mComm(comm) {}
+  RCP<MxComm> getComm() const { return mComm; }
+ private:
+  RCP<MxComm> mComm;
+};
+
+template <size_t DIM>
+class MxGridField {
+ public:
+  MxGridField(std::string name, RCP<MxMap> map, std::vector<double> mask) : mName(name), mMap(map), mMask(mask) {}
+  std::string getName() const { return mName; }
+  RCP<MxMap> getMap() const { return mMap; }
+  // zero the components that are in the map but unused (zero area fraction / zero BC factor);
+  // src/MxGridField.cpp "zeroUnusedComponents", called from src/MxSolver.cpp:65
+  template <typename Scalar>
+  static void zeroUnusedComponents(MxMultiVector<Scalar>& data, MxGridField<DIM> const& field) {
+    if (field.mMask.empty()) return;
+    if (!field.mMaskDev) {
+      field.mMaskDev.reset(new MxMultiVector<double>(field.mMap, 1));
+      field.mMaskDev->setColumn(0, field.mMask);
+    }
+    MX_ABI(mxg_mv_mask_rows(data.raw(), field.mMaskDev->raw()), "MxGridField::zeroUnusedComponents");
+  }
+ private:
+  std::string mName;
+  RCP<MxMap> mMap;
+  std::vector<double> mMask;
+  mutable std::shared_ptr<MxMultiVector<double> > mMaskDev;
+};
+
+template <size_t DIM>
+class MxEMSim {
+ public:
+  MxEMSim(mx::YeeConfig const& cfg, RCP<MxComm> comm, Teuchos::ParameterList pList = Teuchos::ParameterList(),
+          std::shared_ptr<mx::YeeAssembler<double> > assembler = nullptr)
+      : mCfg(cfg), mGrid(comm), mPList(pList),
+        mAsm(assembler ? assembler : std::make_shared<mx::YeeAssembler<double> >(cfg)) {
+    static_assert(DIM == 3, "only the 3-D path is built");
+    addField("bfield", mAsm->bfield(), mAsm->usedMask(), comm);
+    addField("efield", mAsm->efield(), std::vector<double>(), comm);
+    addField("psifield", mAsm->psifield(), std::vector<double>(), comm);
+    mPList.set("has curl null", true);
+  }
+  bool hasPEC() const { return (bool)mCfg.pec; }
+  bool hasDielectric() const { return false; }
+  bool hasMu() const { return false; }
+  bool hasPML() const { return false; }
+  const MxGrid<DIM>& getGrid() const { return mGrid; }
+  Teuchos::ParameterList getParameters() const { return mPList; }
+  void setParameters(Teuchos::ParameterList p) { mPList = p; mPList.set("has curl null", true); }
+  const MxGridField<DIM>& getField(std::string fieldName) const {
+    auto it = mFields.find(fieldName);
+    if (it == mFields.end()) { std::cout << "MxEMSim<" << DIM << ">::getField: field '" << fieldName << "' not found."; throw 1; }
+    return *it->second;
+  }
+  const mx::YeeAssembler<double>& getAssembler() const { return *mAsm; }
+ private:
+  void addField(const char* name, const mx::YeeField& f, std::vector<double> mask, RCP<MxComm> comm) {
+    std::vector<MxIndex> g(f.gids.begin(), f.gids.end());
+    RCP<MxMap> map = rcp(new MxMap(g, comm));
+    mFields[name] = std::make_shared<MxGridField<DIM> >(name, map, mask);
+  }
+  mx::YeeConfig mCfg;
+  MxGrid<DIM> mGrid;
+  Teuchos::ParameterList mPList;
+  std::shared_ptr<mx::YeeAssembler<double> > mAsm;
+  std::map<std::string, std::shared_ptr<MxGridField<DIM> > > mFields;
+};
+
+#endif

@@ -1,0 +1,257 @@
+// The shift-invert magnetic wave operator Anasazi drives (reference src/MxMagWaveOp.h:23-181,
+// src/MxMagWaveOp.cpp:32-273 setup, :826-943 Apply, :1119-1270 checks).
+//
+//   y = P (L - sigma M)^-1 M x,   P = I + G (-D M G)^-1 D M
+//
+// L = vecLapl = curlCurl - gradDiv, M = mRhs (dmA | I), D = divB, G = gradPsi.  The two inner
+// solves run on the GPU (mxg_solve_cg / mxg_solve_gmres, the AztecOO replacement); every vector
+// stays in HBM for the whole eigensolve.
+#ifndef MX_MAG_WAVE_OP
+#define MX_MAG_WAVE_OP
+
+#include <chrono>
+#include <complex>
+
+#include "MxAnasaziMV.hpp"
+#include "MxEMOps.h"
+
+template <size_t DIM, typename Scalar>
+class MxMagWaveOp : public Anasazi::Operator<Scalar> {
+ public:
+  explicit MxMagWaveOp(RCP<MxEMSim<DIM> > sim)
+      : mSim(sim), mBMap(sim->getField("bfield").getMap()), mEMap(sim->getField("efield").getMap()),
+        mPList(sim->getParameters()), pid(sim->getGrid().getComm()->myPID()),
+        mNumVecLinIters(0), mNumScaLinIters(0), mNumApplies(0), mVecCumSolveTime(0), mScaCumSolveTime(0) {
+    mHasCurlNull = (DIM == 3);
+    if (mHasCurlNull) mPsiMap = sim->getField("psifield").getMap();
+    invert = mPList.get("eigensolver : invert", true);
+    blockSize = mPList.get("eigensolver : block size", 1);
+    linTol = mPList.get("linear solver : tol", 1.0e-6);
+    shift = mPList.get("eigensolver : shift", 0.0);
+    verbose = mPList.get("eigensolver : output", 1);
+    if (pid == 0 && verbose) std::cout << "shift is: " << shift << "\n";
+    initMatrices();
+    setShift(Scalar(shift));
+    initWorkVecs();
+  }
+
+  virtual ~MxMagWaveOp() {
+    if (pid == 0 && verbose && mNumApplies > 0) {   // src/MxMagWaveOp.cpp:97-115
+      std::string invType = mPList.get("linear solver : type", "gmres");
+      std::cout << "\n-----------MxMagWaveOp----------\n"
+                << "  Total applications: " << mNumApplies << "\n"
+                << "  VecLapl:\n    - " << invType << " iterations: " << mNumVecLinIters << "\n"
+                << "    - " << invType << " iters/app: " << double(mNumVecLinIters) / mNumApplies << "\n"
+                << "    - " << invType << " time/app: " << mVecCumSolveTime / (blockSize * mNumApplies) << "\n"
+                << "  ScaLapl:\n    - " << invType << " iterations: " << mNumScaLinIters << "\n"
+                << "    - " << invType << " iters/app: " << double(mNumScaLinIters) / mNumApplies << "\n"
+                << "    - " << invType << " time/app: " << mScaCumSolveTime / (blockSize * mNumApplies) << "\n"
+                << "--------------------------------\n\n";
+    }
+  }
+
+  void eigValsToFreqs(std::vector<std::complex<double> > const& eigVals,
+                      std::vector<std::complex<double> >& freqs) const {   // :1253-1270
+    const double lightspeed = 299792458., pi = 3.14159265358979323846;
+    freqs.resize(eigVals.size());
+    for (size_t i = 0; i < eigVals.size(); ++i) {
+      std::complex<double> val = invert ? 1.0 / eigVals[i] + shift : eigVals[i] + shift;
+      freqs[i] = std::sqrt(val) * lightspeed / 2.0 / pi;
+    }
+  }
+
+  MxMap const& getEMap() const { return *mEMap; }
+  MxMap const& getBMap() const { return *mBMap; }
+  MxMap const& getPsiMap() const { return *mPsiMap; }
+  RCP<MxCrsMatrix<Scalar> > getRhs() const { return mRhs; }
+  RCP<MxEMOps<DIM, Scalar> > getOps() const { return mEMOps; }
+
+  void magToElec(MxMultiVector<Scalar> const& mag, MxMultiVector<Scalar>& elec) const {   // :1238-1250
+    mEMOps->getOp("curlB")->apply(mag, elec);
+  }
+
+  void checkDivergences(MxMultiVector<Scalar> const& magVecs, std::vector<double>& residuals) const {   // :1212-1234
+    const size_t nVecs = magVecs.getNumVecs();
+    MxMultiVector<Scalar> b(mBMap, nVecs), psi(mPsiMap, nVecs);
+    mRhs->apply(magVecs, b);
+    mEMOps->getOp("divB")->apply(b, psi);
+    psi.norm2(residuals);
+  }
+
+  // r_i = || curlCurl v_i - k_i^2 M v_i ||_2 / |k_i^2|   (:1119-1209)
+  void checkEigensolution(std::vector<std::complex<double> > const& eigVals, MxMultiVector<Scalar> const& eigVecs,
+                          std::vector<double>& residuals) const {
+    MxMultiVector<Scalar> Aevecs(eigVecs.getMap(), eigVecs.getNumVecs());
+    MxMultiVector<Scalar> Bevecs(eigVecs.getMap(), eigVecs.getNumVecs());
+    mEMOps->getOp("curlCurl")->apply(eigVecs, Aevecs);
+    mRhs->apply(eigVecs, Bevecs);
+    std::vector<std::complex<double> > k2;
+    for (size_t i = 0; i < eigVals.size(); ++i) k2.push_back(invert ? 1.0 / eigVals[i] + shift : eigVals[i] + shift);
+    for (size_t i = 0; i < eigVals.size(); ++i) {
+      Scalar tmp = toScalar(-k2[i]);
+      Aevecs.getVectorNonConst(i, false)->update(tmp, *Bevecs.getVector(i, false), ScalarTraits<Scalar>::one());
+    }
+    Aevecs.norm2(residuals);
+    for (size_t i = 0; i < k2.size(); ++i) residuals[i] /= std::abs(k2[i]);
+  }
+
+  // shiftedVecLapl = vecLapl - shift * mRhs  (:248-255)
+  void setShift(Scalar newShift) {
+    mShiftedVecLapl = rcp(new MxCrsMatrix<Scalar>(mBMap));
+    MxCrsMatrix<Scalar>::matrixMatrixAdd(*mVecLapl, false, ScalarTraits<Scalar>::one(), *mRhs, false, -newShift,
+                                         *mShiftedVecLapl, true);
+    setLinearSolvers();
+  }
+
+  // Anasazi::Operator interface (:826-943)
+  virtual void Apply(Anasazi::MultiVec<Scalar> const& x, Anasazi::MultiVec<Scalar>& y) const {
+    MxAnasaziMV<Scalar> const& x2 = dynamic_cast<MxAnasaziMV<Scalar> const&>(x);
+    MxAnasaziMV<Scalar>& y2 = dynamic_cast<MxAnasaziMV<Scalar>&>(y);
+    if (pid == 0 && verbose > 1) std::cout << "Applying MagWaveOp!\n";
+    mNumApplies++;
+    if (!invert) {
+      if (pid == 0) std::cout << "Non inverse Mag wave op not implemented\n";
+      return;
+    }
+    const size_t nv = x2.getNumVecs();
+    ensureWork(nv);
+    mRhs->apply(x2, y2);                                   // y = M x
+    bWork1->set(ScalarTraits<Scalar>::zero());
+    mxg_ctx* ctx = mBMap->getComm()->getCtx();
+    mxg_solve_info info;
+    auto t0 = std::chrono::steady_clock::now();
+    // first inversion: (L - sigma M) bWork1 = y, to the unscaled true residual linTol
+    MX_ABI(solve(ctx, mShiftedVecLapl->getRawMatrix(), y2.raw(), bWork1->raw(), &info), "MxMagWaveOp::Apply (vecLapl solve)");
+    mNumVecLinIters += info.iters;
+    mVecCumSolveTime += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (pid == 0 && verbose > 1)
+      std::cout << "True residual of vector Laplacian solve: " << info.true_res << "\nNum iters: " << info.iters << "\n";
+    if (!info.converged && pid == 0) std::cout << "MxMagWaveOp: WARNING: vector Laplacian solve stopped at residual " << info.true_res << "\n";
+    if (mHasCurlNull) {
+      // projection: y = bWork1 + G psi, scaLapl psi = D M bWork1
+      mRhs->apply(*bWork1, y2);
+      mEMOps->getOp("divB")->apply(y2, *psiWork1);
+      psiWork2->set(ScalarTraits<Scalar>::zero());
+      t0 = std::chrono::steady_clock::now();
+      MX_ABI(solve(ctx, mScaLapl->getRawMatrix(), psiWork1->raw(), psiWork2->raw(), &info), "MxMagWaveOp::Apply (scaLapl solve)");
+      mNumScaLinIters += info.iters;
+      mScaCumSolveTime += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (pid == 0 && verbose > 1) std::cout << "True residual of scalar Laplacian solve: " << info.true_res << "\n";
+      mEMOps->getOp("gradPsi")->apply(*psiWork2, y2);
+      y2.update(ScalarTraits<Scalar>::one(), *bWork1, ScalarTraits<Scalar>::one());
+    } else {
+      y2 = *bWork1;
+    }
+  }
+
+  int numApplies() const { return mNumApplies; }
+  int numVecLinIters() const { return mNumVecLinIters; }
+  int numScaLinIters() const { return mNumScaLinIters; }
+  double vecSolveTime() const { return mVecCumSolveTime; }
+  double scaSolveTime() const { return mScaCumSolveTime; }
+
+ private:
+  static double toScalarImpl(std::complex<double> z, double*) { return z.real(); }
+  static MxComplex toScalarImpl(std::complex<double> z, MxComplex*) { return z; }
+  static Scalar toScalar(std::complex<double> z) { return toScalarImpl(z, (Scalar*)0); }
+
+  void initMatrices() {   // :138-245
+    mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim));
+    std::vector<std::string> names;
+    names.push_back("curlB");
+    if (mSim->hasPEC()) names.push_back("dmL");
+    names.push_back("curlE");
+    mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true, true, "curlCurl");
+    if (mHasCurlNull) {
+      names.clear();
+      if (mSim->hasPEC()) names.push_back("dmA");
+      names.push_back("divB");
+      if (mSim->hasPEC()) names.push_back("dmVInv");
+      names.push_back("gradPsi");
+      if (mSim->hasPEC()) names.push_back("dmA");
+      mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true, true, "gradDiv");
+      names.clear();
+      names.push_back("curlCurl");
+      names.push_back("gradDiv");
+      std::vector<Scalar> scalars;
+      scalars.push_back(ScalarTraits<Scalar>::one());
+      scalars.push_back(-ScalarTraits<Scalar>::one());
+      mEMOps->addOps(names, scalars, true, "vecLapl");
+      mVecLapl = mEMOps->getOp("vecLapl");
+      mVecLapl->purgeZeros();
+      names.clear();
+      names.push_back("gradPsi");
+      if (mSim->hasPEC()) names.push_back("dmA");
+      names.push_back("divB");
+      mScaLapl = mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true, true, "scaLapl");
+      mScaLapl->scale(-ScalarTraits<Scalar>::one());
+    } else {
+      mVecLapl = mEMOps->getOp("curlCurl");
+    }
+    if (mSim->hasPEC()) mRhs = mEMOps->getOp("dmA");
+    else mRhs = rcp(new MxCrsMatrix<Scalar>(mBMap, ScalarTraits<Scalar>::one()));
+  }
+
+  void initWorkVecs() { ensureWork((size_t)blockSize); }
+  void ensureWork(size_t nv) const {
+    if (bWork1.is_null() || bWork1->getNumVecs() != nv) {
+      bWork1 = rcp(new MxMultiVector<Scalar>(mBMap, nv));
+      if (mHasCurlNull) {
+        psiWork1 = rcp(new MxMultiVector<Scalar>(mPsiMap, nv));
+        psiWork2 = rcp(new MxMultiVector<Scalar>(mPsiMap, nv));
+      }
+    }
+  }
+
+  void setLinearSolvers() {   // :286-355
+    std::string precType = mPList.get("linear solver : prec type", "none");
+    if (precType == "gmg") {
+      if (pid == 0) std::cout << "Using GMRES with geometric multigrid preconditioner.\nNot implemented.\n";
+      exit(EXIT_FAILURE);
+    } else if (precType == "amg" || precType == "ilu" || precType == "jacobi") {
+      // ML / AztecOO-ILU are Trilinos packages; the SpMV-only stand-in is diagonal scaling
+      if (pid == 0 && verbose) std::cout << "MxMagWaveOp: '" << precType << "' preconditioner -> Jacobi (GPU, SpMV-only).\n";
+      mOpts.precond = 1;
+    } else if (precType == "none") {
+      if (pid == 0 && verbose) std::cout << "MxMagWaveOp: WARNING: no preconditioner!\n";
+      mOpts.precond = 0;
+    } else {
+      std::cout << "MxMagWaveOp: Unrecognized preconditioner type '" << precType << "'.\n";
+      exit(EXIT_FAILURE);
+    }
+    std::string invType = mPList.get("linear solver : type", "gmres");
+    if (invType == "gmres") mUseCg = false;
+    else if (invType == "cg") mUseCg = true;
+    else { std::cout << "MxMagWaveOp: solver type '" << invType << "' not implemented.\n"; throw 1; }
+    linBasis = mPList.get("linear solver : basis", 20);
+    mOpts.tol = linTol;
+    mOpts.restart = linBasis;
+    mOpts.max_iters = mPList.get("linear solver : max iters", 0);
+    mOpts.cheb_degree = 0; mOpts.lmin = 0; mOpts.lmax = 0;
+  }
+
+  int solve(mxg_ctx* ctx, mxg_csr* A, mxg_mv* b, mxg_mv* x, mxg_solve_info* info) const {
+    return mUseCg ? mxg_solve_cg(ctx, A, b, x, &mOpts, info) : mxg_solve_gmres(ctx, A, b, x, &mOpts, info);
+  }
+
+  RCP<MxEMSim<DIM> > mSim;
+  RCP<MxMap> mBMap, mEMap, mPsiMap;
+  Teuchos::ParameterList mPList;
+  int pid;
+  bool mHasCurlNull;
+  bool invert;
+  int blockSize;
+  double linTol;
+  double shift;
+  int linBasis;
+  int verbose;
+  bool mUseCg = false;
+  mxg_solve_opts mOpts;
+  mutable int mNumVecLinIters, mNumScaLinIters, mNumApplies;
+  mutable double mVecCumSolveTime, mScaCumSolveTime;
+  RCP<MxCrsMatrix<Scalar> > mVecLapl, mShiftedVecLapl, mScaLapl, mRhs;
+  RCP<MxEMOps<DIM, Scalar> > mEMOps;
+  mutable RCP<MxMultiVector<Scalar> > bWork1, psiWork1, psiWork2;
+};
+
+#endif

@@ -66,7 +66,7 @@ def build_host(force=False):
         return target
     # -ffp-contract=off: assembled matrix values must not depend on FMA contraction
     cmd = ["g++", "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-I" + INCLUDE, "-I" + src_dir] + HOST_SOURCES + \
+           "-I" + INCLUDE, "-I" + os.path.join(INCLUDE, "mx"), "-I" + src_dir] + HOST_SOURCES + \
           ["-o", target, "-L" + LIBDIR, "-lmxg", "-Wl,-rpath,$ORIGIN"]
     _run(cmd, src_dir)
     return target

@@ -26,7 +26,7 @@
 #include <vector>
 
 #include "mx_geometry.hpp"
-#include "mx_sparse.hpp"
+#include "mx/mx_sparse.hpp"
 
 namespace mx {
 

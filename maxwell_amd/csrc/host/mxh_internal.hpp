@@ -12,7 +12,7 @@
 
 struct mxh_sim {
   mx::YeeConfig cfg;
-  std::unique_ptr<mx::YeeAssembler<double>> asmb;
+  std::shared_ptr<mx::YeeAssembler<double>> asmb;
   std::map<std::string, mx::Csr<double>> ops;
   std::map<double, mx::Csr<double>> shifted;
   std::vector<double> mask;

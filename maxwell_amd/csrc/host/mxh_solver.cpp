@@ -1,13 +1,117 @@
-// placeholder until the eigen-driver lands (replaced in the next commit)
+// C ABI over the eigen-driver (include/mxh.h, mxh_solver_*): MxSolver + MxMagWaveOp.
+#include <memory>
+
+#include "mx/MxSolver.h"
 #include "mxh.h"
 #include "mxh_internal.hpp"
+
+struct mxh_solver {
+  RCP<MxComm> comm;
+  RCP<MxEMSim<3> > sim;
+  std::unique_ptr<MxSolver<3, double> > solver;
+  mxh_solver_params params;
+  std::string linType, precType;
+};
+
 extern "C" void mxh_solver_default_params(mxh_solver_params* p) {
-  p->nev = 10; p->basis = 20; p->block_size = 1; p->max_restarts = 100; p->tol = 1e-6; p->shift = 0.0;
-  p->lin_type = "gmres"; p->lin_basis = 40; p->lin_tol = 1e-6; p->prec_type = "none"; p->verbose = 0; p->seed = 12345;
+  // defaults of src/MxProblem.cpp:26-46
+  p->nev = 10; p->basis = 20; p->block_size = 1; p->max_restarts = 100; p->tol = 1.0e-6; p->shift = 0.0;
+  p->lin_type = "gmres"; p->lin_basis = 40; p->lin_tol = 1.0e-6; p->prec_type = "none";
+  p->verbose = 0; p->seed = 12345;
 }
-extern "C" int mxh_solver_create(mxg_ctx*, mxh_sim*, const mxh_solver_params*, mxh_solver**) { mxh_set_error("not implemented"); return 1; }
-extern "C" int mxh_solver_destroy(mxh_solver*) { return 0; }
-extern "C" int mxh_solver_solve(mxh_solver*, int*) { mxh_set_error("not implemented"); return 1; }
-extern "C" int mxh_solver_result(mxh_solver*, int, double*, double*, double*, double*, double*) { return 1; }
-extern "C" int mxh_solver_stats(mxh_solver*, int*, int*, int*, double*, double*, double*) { return 1; }
-extern "C" int mxh_solver_eigvec(mxh_solver*, int, double*) { return 1; }
+
+extern "C" int mxh_solver_create(mxg_ctx* ctx, mxh_sim* sim, const mxh_solver_params* p, mxh_solver** out) {
+  try {
+    if (!ctx || !sim || !p || !out) throw std::runtime_error("mxh_solver_create: NULL argument");
+    std::unique_ptr<mxh_solver> s(new mxh_solver());
+    s->params = *p;
+    s->linType = p->lin_type ? p->lin_type : "gmres";
+    s->precType = p->prec_type ? p->prec_type : "none";
+    s->comm = rcp(new MxComm(ctx));
+    Teuchos::ParameterList pl;
+    pl.set("eigensolver : type", "krylov-schur");
+    pl.set("eigensolver : nev", p->nev);
+    pl.set("eigensolver : basis", p->basis);
+    pl.set("eigensolver : block size", p->block_size);
+    pl.set("eigensolver : max restarts", p->max_restarts);
+    pl.set("eigensolver : tol", p->tol);
+    pl.set("eigensolver : shift", p->shift);
+    pl.set("eigensolver : spectrum", "LM");
+    pl.set("eigensolver : output", p->verbose);
+    pl.set("eigensolver : invert", true);
+    pl.set("linear solver : type", s->linType.c_str());
+    pl.set("linear solver : basis", p->lin_basis);
+    pl.set("linear solver : tol", p->lin_tol);
+    pl.set("linear solver : prec type", s->precType.c_str());
+    s->sim = rcp(new MxEMSim<3>(sim->cfg, s->comm, pl, sim->asmb));
+    s->solver.reset(new MxSolver<3, double>(s->sim, pl));
+    *out = s.release();
+    return 0;
+  } catch (const std::exception& e) {
+    mxh_set_error(e.what());
+    return 1;
+  } catch (int) {
+    mxh_set_error(std::string("MxSolver setup failed: ") + mxg_last_error());
+    return 1;
+  }
+}
+
+extern "C" int mxh_solver_destroy(mxh_solver* s) {
+  delete s;
+  return 0;
+}
+
+extern "C" int mxh_solver_solve(mxh_solver* s, int* nconv) {
+  try {
+    s->solver->solve();
+    if (nconv) *nconv = (int)s->solver->eigenvalues().size();
+    return 0;
+  } catch (const std::exception& e) {
+    mxh_set_error(e.what());
+    return 1;
+  } catch (int) {
+    mxh_set_error(std::string("MxSolver::solve failed: ") + mxg_last_error());
+    return 1;
+  }
+}
+
+extern "C" int mxh_solver_result(mxh_solver* s, int i, double theta[2], double k2[2], double freq[2],
+                                 double* residual, double* divergence) {
+  const auto& ev = s->solver->eigenvalues();
+  if (i < 0 || i >= (int)ev.size()) {
+    mxh_set_error("mxh_solver_result: index out of range");
+    return 1;
+  }
+  const std::complex<double> kk = 1.0 / ev[i] + s->params.shift;   // src/MxMagWaveOp.cpp:1171-1179
+  if (theta) { theta[0] = ev[i].real(); theta[1] = ev[i].imag(); }
+  if (k2) { k2[0] = kk.real(); k2[1] = kk.imag(); }
+  if (freq) { freq[0] = s->solver->frequencies()[i].real(); freq[1] = s->solver->frequencies()[i].imag(); }
+  if (residual) *residual = s->solver->residuals()[i];
+  if (divergence) *divergence = s->solver->divergences()[i];
+  return 0;
+}
+
+extern "C" int mxh_solver_stats(mxh_solver* s, int* num_applies, int* vec_lin_iters, int* sca_lin_iters,
+                                double* vec_solve_seconds, double* sca_solve_seconds,
+                                double* eigensolve_seconds) {
+  const auto& op = s->solver->waveOp();
+  if (num_applies) *num_applies = op.numApplies();
+  if (vec_lin_iters) *vec_lin_iters = op.numVecLinIters();
+  if (sca_lin_iters) *sca_lin_iters = op.numScaLinIters();
+  if (vec_solve_seconds) *vec_solve_seconds = op.vecSolveTime();
+  if (sca_solve_seconds) *sca_solve_seconds = op.scaSolveTime();
+  if (eigensolve_seconds) *eigensolve_seconds = s->solver->eigensolveSeconds();
+  return 0;
+}
+
+extern "C" int mxh_solver_eigvec(mxh_solver* s, int i, double* out) {
+  try {
+    std::vector<double> col;
+    s->solver->magneticEigenvectors()->getColumn((size_t)i, col);
+    std::copy(col.begin(), col.end(), out);
+    return 0;
+  } catch (...) {
+    mxh_set_error("mxh_solver_eigvec failed");
+    return 1;
+  }
+}
