@@ -35,6 +35,28 @@ int mxh_sim_create(const int n[3], const double origin[3], const double size[3],
                    int strict, mxh_sim** out);
 int mxh_sim_destroy(mxh_sim* s);
 
+/* ---------------------------------------------------------------------------------------
+ * Domain decomposition: one GPU per MxGridDomain box (src/MxGrid.cpp:100-193)
+ * ------------------------------------------------------------------------------------- */
+/* MxGrid::partition + getGridDomain: process grid minimising sum_i p_i / n_i over all ordered
+ * factorisations of nranks (first minimum wins), and the cell box [lo, hi) of `rank`
+ * (the last rank along an axis also owns the upper node layer, hi = n + 1). */
+int mxh_partition(const int n[3], int nranks, int rank, int proc_grid[3], int box_lo[3], int box_hi[3]);
+/* rank owning global cell (i, j, k) under that partition */
+int mxh_owner_of_cell(const int n[3], const int proc_grid[3], const int cell[3]);
+/* like mxh_sim_create, for the sub-box [box_lo, box_hi) of this rank: operators are assembled on
+ * the box plus a two-cell halo, so their owned rows are exact without communication */
+int mxh_sim_create_box(const int n[3], const double origin[3], const double size[3],
+                       const char* const lower[3], const char* const upper[3], const char* pec_shape,
+                       int strict, const int box_lo[3], const int box_hi[3], mxh_sim** out);
+/* owned rows of a named operator (or of vecLapl - shift*mRhs when name == "shifted") with GLOBAL
+ * column ids: the row-partitioned form Epetra would hold.  row_gids / col_field_owned_gids are the
+ * ascending global ids of the owned row entries and of the owned entries of the column field. */
+int mxh_sim_dist_op(mxh_sim* s, const char* name, double shift, int64_t* nrows, int64_t* nnz,
+                    const int64_t** rowptr, const int64_t** col_gids, const double** vals,
+                    const int64_t** row_gids, int64_t* n_owned_cols, const int64_t** col_field_owned_gids,
+                    int* col_ncomp);
+
 /* Borrowed views (valid until mxh_sim_destroy) of a named operator in local CSR form:
  * curlE curlB divB gradPsi dmA dmL dmVInv curlCurl gradDiv vecLapl scaLapl mRhs
  * (MxEMOps::getOp, src/MxEMOps.cpp:171-183; MxMagWaveOp::initMatrices, src/MxMagWaveOp.cpp:138-245) */

@@ -6,6 +6,7 @@
 hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the CPU-only
 container; the built .so files travel to the GPU box with the repository snapshot.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -20,11 +21,25 @@ DEVICE_SOURCES = ["mxg_ctx.hip", "mxg_mv.hip", "mxg_csr.hip", "mxg_solve.hip"]
 HOST_SOURCES = ["mx_geometry.cpp", "mx_yee.cpp", "mxh_sim.cpp", "mxh_solver.cpp"]
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
+def _digest(sources, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for s in sorted(sources):
+        if os.path.isfile(s):
+            h.update(os.path.basename(s).encode())
+            h.update(open(s, "rb").read())
+    return h.hexdigest()
+
+
+def _stale(target, sources, extra=""):
+    """Content hash, not mtime: the snapshot copied to the GPU box does not keep timestamps."""
+    stamp = target + ".stamp"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    return open(stamp).read().strip() != _digest(sources, extra)
+
+
+def _write_stamp(target, sources, extra=""):
+    open(target + ".stamp", "w").write(_digest(sources, extra))
 
 
 def _deps(directory, extra=()):
@@ -37,15 +52,17 @@ def _deps(directory, extra=()):
 
 
 def _run(cmd, cwd):
-    print("+", " ".join(cmd), flush=True)
-    subprocess.run(cmd, cwd=cwd, check=True)
+    # everything goes to stderr: bench.py must keep stdout for its single JSON line
+    print("+", " ".join(cmd), file=sys.stderr, flush=True)
+    subprocess.run(cmd, cwd=cwd, check=True, stdout=sys.stderr)
 
 
 def build_device(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     src_dir = os.path.join(CSRC, "device")
     target = os.path.join(LIBDIR, "libmxg.so")
-    if not force and not _newer(target, _deps(src_dir)):
+    deps = [d for d in _deps(src_dir) if not d.endswith(".so")]
+    if not force and not _stale(target, deps):
         return target
     hipcc = os.path.join(ROCM, "bin", "hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
@@ -54,6 +71,7 @@ def build_device(force=False):
           ["-o", target, "-L" + os.path.join(ROCM, "lib"), "-lrccl",
            "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     _run(cmd, src_dir)
+    _write_stamp(target, deps)
     return target
 
 
@@ -62,13 +80,16 @@ def build_host(force=False):
     src_dir = os.path.join(CSRC, "host")
     target = os.path.join(LIBDIR, "libmxhost.so")
     libmxg = os.path.join(LIBDIR, "libmxg.so")
-    if not force and not _newer(target, _deps(src_dir, [libmxg])):
+    deps = [d for d in _deps(src_dir) if not d.endswith(".so")]
+    dev_stamp = open(libmxg + ".stamp").read() if os.path.exists(libmxg + ".stamp") else ""
+    if not force and not _stale(target, deps, dev_stamp):
         return target
     # -ffp-contract=off: assembled matrix values must not depend on FMA contraction
     cmd = ["g++", "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-I" + INCLUDE, "-I" + os.path.join(INCLUDE, "mx"), "-I" + src_dir] + HOST_SOURCES + \
           ["-o", target, "-L" + LIBDIR, "-lmxg", "-Wl,-rpath,$ORIGIN"]
     _run(cmd, src_dir)
+    _write_stamp(target, deps, dev_stamp)
     return target
 
 

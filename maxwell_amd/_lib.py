@@ -88,6 +88,15 @@ MXH_SIGNATURES = {
     "mxh_sim_create": (C.c_int, [C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_char_p),
                                  C.POINTER(C.c_char_p), C.c_char_p, C.c_int, C.POINTER(vp)]),
     "mxh_sim_destroy": (C.c_int, [vp]),
+    "mxh_partition": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                C.POINTER(C.c_int)]),
+    "mxh_owner_of_cell": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mxh_sim_create_box": (C.c_int, [C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_char_p),
+                                     C.POINTER(C.c_char_p), C.c_char_p, C.c_int, C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.POINTER(vp)]),
+    "mxh_sim_dist_op": (C.c_int, [vp, C.c_char_p, C.c_double, c_i64p, c_i64p, C.POINTER(c_i64p),
+                                  C.POINTER(c_i64p), C.POINTER(c_dp), C.POINTER(c_i64p), c_i64p,
+                                  C.POINTER(c_i64p), c_ip]),
     "mxh_sim_op": (C.c_int, [vp, C.c_char_p, c_i64p, c_i64p, c_i64p, C.POINTER(c_i64p),
                              C.POINTER(c_i32p), C.POINTER(c_dp)]),
     "mxh_sim_shifted": (C.c_int, [vp, C.c_double, c_i64p, c_i64p, C.POINTER(c_i64p),

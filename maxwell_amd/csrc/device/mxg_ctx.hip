@@ -48,8 +48,8 @@ extern "C" int mxg_ctx_create(int device, int rank, int nranks, const void* nccl
   MXG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MXG_HIP(hipEventCreate(&c->ev0));
   MXG_HIP(hipEventCreate(&c->ev1));
-  if (nranks > 1) {
-    MXG_CHECK(nccl_unique_id != nullptr, "mxg_ctx_create: nranks > 1 needs an RCCL unique id");
+  MXG_CHECK(nranks == 1 || nccl_unique_id != nullptr, "mxg_ctx_create: nranks > 1 needs an RCCL unique id");
+  if (nccl_unique_id != nullptr) {   // also for nranks == 1: a 1-rank communicator (self send/recv works)
     ncclUniqueId id;
     memcpy(&id, nccl_unique_id, sizeof(id));
     MXG_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));

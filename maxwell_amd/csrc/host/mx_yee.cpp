@@ -68,6 +68,19 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
     P_.lbc[0][i] = psiBc(cfg.lower[i]);
     P_.ubc[0][i] = psiBc(cfg.upper[i]);
   }
+  windowed_ = false;
+  for (int i = 0; i < 3; ++i) {
+    periodicAxis_[i] = cfg.lower[i] == BC_PERIODIC && cfg.upper[i] == BC_PERIODIC;
+    const int lo = cfg.boxLo[i], hi = cfg.boxHi[i] < 0 ? n_[i] + 1 : cfg.boxHi[i];
+    if (lo < 0 || hi > n_[i] + 1 || lo >= hi) throw std::runtime_error("YeeAssembler: bad owned box");
+    cfg_.boxLo[i] = lo; cfg_.boxHi[i] = hi;
+    splitAxis_[i] = !(lo == 0 && hi == n_[i] + 1);
+    if (!splitAxis_[i]) { wlo_[i] = 0; whi_[i] = n_[i] + 1; continue; }   // whole axis
+    windowed_ = true;
+    wlo_[i] = lo - cfg.halo; whi_[i] = hi + cfg.halo;
+    if (!periodicAxis_[i]) { wlo_[i] = std::max(wlo_[i], 0); whi_[i] = std::min(whi_[i], n_[i] + 1); }
+    else if (whi_[i] - wlo_[i] > n_[i]) throw std::runtime_error("YeeAssembler: box + halo wraps onto itself");
+  }
   Tick tick;
   if (cfg_.pec) {
     addShapeRep(B_);
@@ -76,14 +89,15 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
   }
   tick("fractions");
   // "any used component keeps the whole B cell" lookup over the extended lattice
-  const int64_t next = (int64_t)(n_[0] + 3) * (n_[1] + 3) * (n_[2] + 3);
-  bcellUsed_.resize(next);
+  bcellUsed_.resize(extSize());
 #pragma omp parallel for schedule(static)
-  for (int i = -1; i <= n_[0] + 1; ++i)
-    for (int j = -1; j <= n_[1] + 1; ++j)
-      for (int k = -1; k <= n_[2] + 1; ++k) {
-        const int c[3] = {i, j, k};
-        bcellUsed_[extIndex(c)] = baseUse(B_, 0, c) || baseUse(B_, 1, c) || baseUse(B_, 2, c);
+  for (int i = wlo_[0] - 1; i <= whi_[0]; ++i)
+    for (int j = wlo_[1] - 1; j <= whi_[1]; ++j)
+      for (int k = wlo_[2] - 1; k <= whi_[2]; ++k) {
+        const int u[3] = {i, j, k};
+        int c[3];
+        canon(u, c);
+        bcellUsed_[extIndex(u)] = baseUse(B_, 0, c) || baseUse(B_, 1, c) || baseUse(B_, 2, c);
       }
   tick("bcellUsed");
   setMap(B_);
@@ -140,23 +154,25 @@ void YeeAssembler<S>::interior(const YeeField& F, int comp, const int c[3], int 
 template <typename S>
 double YeeAssembler<S>::fracAt(const YeeField& F, int comp, const int c[3]) const {
   if (F.frac.empty()) return 1.0;                             // src/MxGridField.hpp:274-277
-  return F.frac[comp][extIndex(c)];
+  const int64_t e = extIndex(c);
+  return e < 0 ? 0.0 : F.frac[comp][e];                        // outside the window: unknown -> unused
 }
 
 template <typename S>
 void YeeAssembler<S>::addShapeRep(YeeField& F) {               // src/MxGridField.cpp:193-226
   const Shape& shape = *cfg_.pec;
-  const int64_t next = (int64_t)(n_[0] + 3) * (n_[1] + 3) * (n_[2] + 3);
+  const int64_t next = extSize();
   F.frac.assign(F.ncomp, UVec<double>());
   for (int comp = 0; comp < F.ncomp; ++comp) {
     UVec<double>& fr = F.frac[comp];
     fr.resize(next);
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int i = -1; i <= n_[0] + 1; ++i)
-      for (int j = -1; j <= n_[1] + 1; ++j)
-        for (int k = -1; k <= n_[2] + 1; ++k) {
-          const int c[3] = {i, j, k};
-          int ic[3];
+    for (int i = wlo_[0] - 1; i <= whi_[0]; ++i)
+      for (int j = wlo_[1] - 1; j <= whi_[1]; ++j)
+        for (int k = wlo_[2] - 1; k <= whi_[2]; ++k) {
+          const int u[3] = {i, j, k};
+          int c[3], ic[3];
+          canon(u, c);
           interior(F, comp, c, ic);
           Vec3 p;                                              // calcCompFrac, src/MxGridField.hpp:177-183
           for (int a = 0; a < 3; ++a)
@@ -165,7 +181,7 @@ void YeeAssembler<S>::addShapeRep(YeeField& F) {               // src/MxGridFiel
           if (&F == &B_) f = rectFraction(shape, p, comp, d_[(comp + 1) % 3], d_[(comp + 2) % 3]);
           else if (&F == &E_) f = segmentFraction(shape, p, comp, d_[comp]);
           else f = boxFraction(shape, p, d_[0], d_[1], d_[2]);
-          fr[extIndex(c)] = f;
+          fr[extIndex(u)] = f;
         }
   }
 }
@@ -189,7 +205,8 @@ bool YeeAssembler<S>::baseUse(const YeeField& F, int comp, const int c[3]) const
 
 template <typename S>
 bool YeeAssembler<S>::bUse(const int c[3]) const {             // src/MxYeeFitBField.cpp:63-80
-  return bcellUsed_[extIndex(c)] != 0;
+  const int64_t e = extIndex(c);
+  return e >= 0 && bcellUsed_[e] != 0;
 }
 
 template <typename S>
@@ -263,24 +280,40 @@ int64_t YeeAssembler<S>::gid(const YeeField& F, int comp, const int c[3]) const 
 
 template <typename S>
 void YeeAssembler<S>::setMap(YeeField& F) {                     // src/MxGridField.cpp:256-297
-  const int64_t nnode = (int64_t)(n_[0] + 1) * (n_[1] + 1) * (n_[2] + 1);
-  F.lidOfGid.resize(nnode * F.ncomp);
-  UVec<uint8_t> keep(nnode * F.ncomp);
+  // every window cell that is a lattice node of the global grid, in window C order (== ascending
+  // global id when the window is the whole grid); entries of the owned box are flagged
+  const int64_t nwin = (int64_t)(whi_[0] - wlo_[0]) * (whi_[1] - wlo_[1]) * (whi_[2] - wlo_[2]);
+  F.lidOfWin.resize(nwin * F.ncomp);
+  UVec<uint8_t> keep(nwin * F.ncomp);
 #pragma omp parallel for schedule(static)
-  for (int i = 0; i <= n_[0]; ++i)
-    for (int j = 0; j <= n_[1]; ++j)
-      for (int k = 0; k <= n_[2]; ++k) {
-        const int c[3] = {i, j, k};
-        const int64_t g = cellToGlobal(c);
-        for (int comp = 0; comp < F.ncomp; ++comp) keep[g * F.ncomp + comp] = use(F, comp, c);
-      }
+  for (int64_t w = 0; w < nwin; ++w) {
+    int u[3], c[3];
+    winCell(w, u);
+    canon(u, c);
+    for (int comp = 0; comp < F.ncomp; ++comp) keep[w * F.ncomp + comp] = use(F, comp, c);
+  }
   int64_t count = 0;
-  for (int64_t g = 0; g < nnode * F.ncomp; ++g) count += keep[g];
-  F.gids.resize(count);
+  for (int64_t q = 0; q < nwin * F.ncomp; ++q) count += keep[q];
+  F.gids.resize(count); F.wcell.resize(count); F.owned.resize(count);
   count = 0;
-  for (int64_t g = 0; g < nnode * F.ncomp; ++g) {
-    if (keep[g]) { F.lidOfGid[g] = (int32_t)count; F.gids[count++] = g; }
-    else F.lidOfGid[g] = -1;
+  for (int64_t w = 0; w < nwin; ++w) {
+    int u[3], c[3];
+    winCell(w, u);
+    canon(u, c);
+    bool own = true;   // ownership follows the canonical cell (node n of a split periodic axis is node 0)
+    for (int i = 0; i < 3; ++i) own = own && c[i] >= cfg_.boxLo[i] && c[i] < cfg_.boxHi[i];
+    for (int comp = 0; comp < F.ncomp; ++comp) {
+      const int64_t q = w * F.ncomp + comp;
+      if (keep[q]) {
+        F.lidOfWin[q] = (int32_t)count;
+        F.gids[count] = gid(F, comp, c);
+        F.wcell[count] = (int32_t)w;
+        F.owned[count] = own;
+        ++count;
+      } else {
+        F.lidOfWin[q] = -1;
+      }
+    }
   }
 }
 
@@ -296,18 +329,20 @@ Csr<S> YeeAssembler<S>::assemble(const YeeField& rowF, const YeeField& colF, boo
   bool bad = false;
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < nrows; ++r) {
-    const int64_t g = rowF.gids[r];
-    const int comp = (int)(g % rowF.ncomp);
-    int cell[3];
-    globalToCell(g / rowF.ncomp, cell);
+    const int comp = (int)(rowF.gids[r] % rowF.ncomp);
+    int ucell[3], cell[3];
+    winCell(rowF.wcell[r], ucell);
+    canon(ucell, cell);
     if (skipDeadRows && factor(rowF, comp, cell) == std::complex<double>(0.0)) { cnt[r] = 0; continue; }
     int n = 0;
     for (const Entry& e : stencil[comp]) {
       const int c[3] = {cell[0] + e.off[0], cell[1] + e.off[1], cell[2] + e.off[2]};
       const std::complex<double> f = factor(colF, e.comp, c);
       if (f == std::complex<double>(0.0)) continue;           // `if (factors[i] != 0)` in every assembler
-      const int32_t lid = colF.lidOfGid[gid(colF, e.comp, c)];
-      if (lid < 0) { bad = true; continue; }
+      int ic[3];
+      interior(colF, e.comp, c, ic);
+      const int32_t lid = lidOf(colF, e.comp, ic);
+      if (lid < 0) { if (!windowed_) bad = true; continue; }   // windowed: beyond the halo, row is discarded later
       cols[r * maxe + n] = lid;
       vals[r * maxe + n] = toScalar(f) * S(e.val);
       ++n;
@@ -406,10 +441,10 @@ Csr<S> YeeAssembler<S>::fracs(const YeeField& F, bool inverse) const {   // src/
   UVec<S> d(F.gids.size());
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < (int64_t)F.gids.size(); ++r) {
-    const int64_t g = F.gids[r];
-    int cell[3];
-    globalToCell(g / F.ncomp, cell);
-    double v = fracAt(F, (int)(g % F.ncomp), cell);
+    int ucell[3], cell[3];
+    winCell(F.wcell[r], ucell);
+    canon(ucell, cell);
+    double v = fracAt(F, (int)(F.gids[r] % F.ncomp), cell);
     if (inverse) v = (v == 0.0) ? 0.0 : 1.0 / v;
     d[r] = S(v);
   }
@@ -420,10 +455,10 @@ template <typename S>
 std::vector<double> YeeAssembler<S>::usedMask() const {
   std::vector<double> m(B_.gids.size());
   for (int64_t r = 0; r < (int64_t)B_.gids.size(); ++r) {
-    const int64_t g = B_.gids[r];
-    int cell[3];
-    globalToCell(g / 3, cell);
-    m[r] = factor(B_, (int)(g % 3), cell) == std::complex<double>(0.0) ? 0.0 : 1.0;
+    int ucell[3], cell[3];
+    winCell(B_.wcell[r], ucell);
+    canon(ucell, cell);
+    m[r] = factor(B_, (int)(B_.gids[r] % 3), cell) == std::complex<double>(0.0) ? 0.0 : 1.0;
   }
   return m;
 }
@@ -467,6 +502,33 @@ std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps() const {   // src/MxMagW
   o["scaLapl"] = sl;
   if (pec) o["mRhs"] = o["dmA"];                                           // :233-236
   else o["mRhs"] = diagonal<S>(UVec<S>(B_.gids.size(), S(1.0)));    // :240-241
+  return o;
+}
+
+template <typename S>
+UVec<int64_t> YeeAssembler<S>::ownedGids(const YeeField& F) const {
+  UVec<int64_t> out;
+  for (size_t r = 0; r < F.gids.size(); ++r) if (F.owned[r]) out.push_back(F.gids[r]);
+  return out;
+}
+
+template <typename S>
+Csr<S> YeeAssembler<S>::ownedRows(const Csr<S>& m, const YeeField& rowF) const {
+  Csr<S> o;
+  o.ncols = m.ncols;
+  std::vector<int64_t> rows;
+  for (int64_t r = 0; r < m.nrows; ++r) if (rowF.owned[r]) rows.push_back(r);
+  o.nrows = (int64_t)rows.size();
+  o.rowptr.resize(o.nrows + 1);
+  o.rowptr[0] = 0;
+  for (int64_t i = 0; i < o.nrows; ++i) o.rowptr[i + 1] = o.rowptr[i] + (m.rowptr[rows[i] + 1] - m.rowptr[rows[i]]);
+  o.col.resize(o.rowptr[o.nrows]);
+  o.val.resize(o.rowptr[o.nrows]);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < o.nrows; ++i) {
+    std::copy(m.col.begin() + m.rowptr[rows[i]], m.col.begin() + m.rowptr[rows[i] + 1], o.col.begin() + o.rowptr[i]);
+    std::copy(m.val.begin() + m.rowptr[rows[i]], m.val.begin() + m.rowptr[rows[i] + 1], o.val.begin() + o.rowptr[i]);
+  }
   return o;
 }
 

@@ -45,6 +45,13 @@ struct YeeConfig {
   // MxYeeFitEField/MxYeePsiField::getCompFactor (drops periodic wrap entries of curlE at the
   // upper boundary); false: test the interiorised cell
   bool strict = true;
+  // Distributed assembly (one GPU per MxGridDomain box, src/MxGrid.cpp:171-193): the cells this
+  // rank owns, [boxLo, boxHi) per axis; boxHi[i] < 0 means the whole axis, [0, n+1).  The
+  // assembler works on the box grown by `halo` cells wherever the axis is split, so the owned rows
+  // of every product (curlCurl, gradDiv, vecLapl, scaLapl) are exact without any communication.
+  int boxLo[3] = {0, 0, 0};
+  int boxHi[3] = {-1, -1, -1};
+  int halo = 2;
 };
 
 struct YeeField {
@@ -53,8 +60,10 @@ struct YeeField {
   bool xi0[3][3];                 // cell-relative coordinate == 0 along axis i for component c
   int lbc[3][3], ubc[3][3];       // CompBc per component and axis
   std::vector<UVec<double>> frac;   // per component over the extended lattice; empty: no region
-  UVec<int64_t> gids;             // sorted global ids of the map
-  UVec<int32_t> lidOfGid;         // dense lookup over ncomp * (N+1)^3, -1 if absent
+  UVec<int64_t> gids;             // global ids of the (window-)map entries; ascending on the owned box
+  UVec<int32_t> wcell;            // window cell index of every map entry
+  UVec<uint8_t> owned;            // 1 if the entry's cell lies in the owned box
+  UVec<int32_t> lidOfWin;         // dense lookup over ncomp * window cells, -1 if absent
 };
 
 template <typename S>
@@ -87,6 +96,13 @@ class YeeAssembler {
   int64_t cellToGlobal(const int c[3]) const;
   void globalToCell(int64_t idx, int c[3]) const;
 
+  // distributed helpers: true if the assembler works on a sub-box
+  bool isWindowed() const { return windowed_; }
+  // rows of the owned box only (ascending global id); columns stay window-local
+  Csr<S> ownedRows(const Csr<S>& m, const YeeField& rowF) const;
+  // global ids of the owned entries of a field (ascending) and of every window entry
+  UVec<int64_t> ownedGids(const YeeField& F) const;
+
  private:
   YeeConfig cfg_;
   int n_[3];
@@ -96,8 +112,58 @@ class YeeAssembler {
   YeeField B_, E_, P_;
   UVec<uint8_t> bcellUsed_;  // extended lattice
 
+  bool windowed_;
+  bool periodicAxis_[3];
+  bool splitAxis_[3];
+  // canonical image of a window coordinate: on a split periodic axis, window cells beyond the seam
+  // stand for the cells of the next period (cell n+1 is cell 1, node n is node 0), so everything
+  // stored for them is evaluated at the wrapped coordinate; a whole axis keeps the reference's
+  // lattice 0..n with its special upper node layer
+  void canon(const int u[3], int c[3]) const {
+    for (int i = 0; i < 3; ++i)
+      c[i] = (periodicAxis_[i] && splitAxis_[i]) ? ((u[i] % n_[i]) + n_[i]) % n_[i] : u[i];
+  }
+  int wlo_[3], whi_[3];     // window [wlo, whi) in unwrapped cell coordinates
+  // window-unwrapped coordinate of cell c (wrapped or not) inside [wlo - g, whi + g); false if outside
+  bool toWin(const int c[3], int g, int u[3]) const {
+    for (int i = 0; i < 3; ++i) {
+      const int lo = wlo_[i] - g, hi = whi_[i] + g;
+      int v = c[i];
+      if (v < lo || v >= hi) {
+        if (!periodicAxis_[i]) return false;
+        if (v - n_[i] >= lo && v - n_[i] < hi) v -= n_[i];
+        else if (v + n_[i] >= lo && v + n_[i] < hi) v += n_[i];
+        else return false;
+      }
+      u[i] = v;
+    }
+    return true;
+  }
+  // index into the extended lattice (window + one guard cell), -1 if outside
   int64_t extIndex(const int c[3]) const {
-    return ((int64_t)(c[0] + 1) * (n_[1] + 3) + (c[1] + 1)) * (n_[2] + 3) + (c[2] + 1);
+    int u[3];
+    if (!toWin(c, 1, u)) return -1;
+    return ((int64_t)(u[0] - wlo_[0] + 1) * (whi_[1] - wlo_[1] + 2) + (u[1] - wlo_[1] + 1)) * (whi_[2] - wlo_[2] + 2) +
+           (u[2] - wlo_[2] + 1);
+  }
+  int64_t extSize() const {
+    return (int64_t)(whi_[0] - wlo_[0] + 2) * (whi_[1] - wlo_[1] + 2) * (whi_[2] - wlo_[2] + 2);
+  }
+  // index into the window lattice, -1 if outside
+  int64_t winIndex(const int c[3]) const {
+    int u[3];
+    if (!toWin(c, 0, u)) return -1;
+    return ((int64_t)(u[0] - wlo_[0]) * (whi_[1] - wlo_[1]) + (u[1] - wlo_[1])) * (whi_[2] - wlo_[2]) + (u[2] - wlo_[2]);
+  }
+  void winCell(int64_t idx, int u[3]) const {
+    const int n1 = whi_[1] - wlo_[1], n2 = whi_[2] - wlo_[2];
+    u[2] = (int)(idx % n2) + wlo_[2];
+    u[1] = (int)((idx / n2) % n1) + wlo_[1];
+    u[0] = (int)(idx / ((int64_t)n1 * n2)) + wlo_[0];
+  }
+  int32_t lidOf(const YeeField& F, int comp, const int c[3]) const {   // c: any image of the cell
+    const int64_t w = winIndex(c);
+    return w < 0 ? -1 : F.lidOfWin[w * F.ncomp + comp];
   }
   void interior(const YeeField& F, int comp, const int c[3], int out[3]) const;
   double fracAt(const YeeField& F, int comp, const int c[3]) const;

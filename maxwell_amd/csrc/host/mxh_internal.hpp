@@ -17,6 +17,12 @@ struct mxh_sim {
   std::map<double, mx::Csr<double>> shifted;
   std::vector<double> mask;
   double setup_seconds = 0.0;
+  // distributed exports (kept alive for the borrowed pointers)
+  struct DistOp {
+    mx::UVec<int64_t> rowptr, colgid, rowgid, colowned;
+    mx::UVec<double> vals;
+  };
+  std::map<std::string, DistOp> dist;
 };
 
 void mxh_set_error(const std::string& s);

@@ -1,6 +1,9 @@
 // C ABI over the host-side assembler (include/mxh.h, mxh_sim_*).
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <sstream>
@@ -69,6 +72,13 @@ std::shared_ptr<const mx::Shape> mxh_parse_shape(const char* spec) {
 extern "C" int mxh_sim_create(const int n[3], const double origin[3], const double size[3],
                               const char* const lower[3], const char* const upper[3],
                               const char* pec_shape, int strict, mxh_sim** out) {
+  return mxh_sim_create_box(n, origin, size, lower, upper, pec_shape, strict, nullptr, nullptr, out);
+}
+
+extern "C" int mxh_sim_create_box(const int n[3], const double origin[3], const double size[3],
+                                  const char* const lower[3], const char* const upper[3],
+                                  const char* pec_shape, int strict, const int box_lo[3],
+                                  const int box_hi[3], mxh_sim** out) {
   try {
     if (!n || !origin || !size || !out) throw std::runtime_error("mxh_sim_create: NULL argument");
     mx::YeeConfig cfg;
@@ -80,6 +90,8 @@ extern "C" int mxh_sim_create(const int n[3], const double origin[3], const doub
     }
     cfg.pec = mxh_parse_shape(pec_shape);
     cfg.strict = strict != 0;
+    if (box_lo && box_hi)
+      for (int i = 0; i < 3; ++i) { cfg.boxLo[i] = box_lo[i]; cfg.boxHi[i] = box_hi[i]; }
     const auto t0 = std::chrono::steady_clock::now();
     mxh_sim* s = new mxh_sim();
     s->cfg = cfg;
@@ -160,3 +172,142 @@ extern "C" int mxh_sim_used_mask(mxh_sim* s, int64_t* n, const double** mask) {
 }
 
 extern "C" double mxh_sim_setup_seconds(const mxh_sim* s) { return s->setup_seconds; }
+
+// ---------------------------------------------------------------------------------------
+// domain decomposition (MxGrid::partition / getGridDomain, src/MxGrid.cpp:100-193;
+// MxUtil::unorderedFactorizations / permutations, src/MxUtil.hpp:199-286)
+// ---------------------------------------------------------------------------------------
+namespace {
+
+std::vector<std::vector<size_t>> unorderedFactorizations(size_t val, size_t maxFac) {
+  std::vector<std::vector<size_t>> res;
+  std::vector<size_t> div;
+  for (size_t i = 2; i <= val; ++i) if (val % i == 0) div.push_back(i);
+  if (div.empty()) { res.push_back(div); return res; }
+  for (size_t d : div) {
+    if (d > maxFac) continue;
+    for (auto& sub : unorderedFactorizations(val / d, d)) {
+      std::vector<size_t> fac(1, d);
+      fac.insert(fac.end(), sub.begin(), sub.end());
+      res.push_back(fac);
+    }
+  }
+  return res;
+}
+
+std::vector<std::vector<size_t>> permutations(const std::vector<size_t>& v) {
+  std::vector<std::vector<size_t>> res;
+  const size_t size = v.size();
+  if (size == 1) { res.push_back(v); return res; }
+  std::vector<size_t> done;
+  for (size_t i = 0; i < size; ++i) {
+    const size_t cur = v[i];
+    if (std::find(done.begin(), done.end(), cur) != done.end()) continue;
+    std::vector<size_t> subset;
+    for (size_t j = i + 1; j < i + size; ++j) subset.push_back(v[j % size]);
+    for (auto& sp : permutations(subset)) {
+      std::vector<size_t> perm(1, cur);
+      perm.insert(perm.end(), sp.begin(), sp.end());
+      res.push_back(perm);
+    }
+    done.push_back(cur);
+  }
+  return res;
+}
+
+void procGridOf(const int n[3], int nranks, int pg[3]) {
+  std::vector<std::vector<size_t>> all = nranks == 1 ? std::vector<std::vector<size_t>>(1, std::vector<size_t>(1, 1))
+                                                     : unorderedFactorizations((size_t)nranks, (size_t)nranks);
+  std::vector<std::vector<size_t>> decomps;
+  for (auto fac : all) {
+    if (fac.size() > 3) continue;
+    while (fac.size() < 3) fac.push_back(1);
+    for (auto& p : permutations(fac)) decomps.push_back(p);
+  }
+  double minRatio = 0;
+  size_t best = 0;
+  for (size_t i = 0; i < decomps.size(); ++i) {
+    double ratio = 0;
+    for (int j = 0; j < 3; ++j) ratio += double(decomps[i][j]) / double(n[j]);
+    if (i == 0 || ratio < minRatio) { minRatio = ratio; best = i; }
+  }
+  for (int j = 0; j < 3; ++j) pg[j] = (int)decomps[best][j];
+}
+
+}  // namespace
+
+extern "C" int mxh_partition(const int n[3], int nranks, int rank, int proc_grid[3], int box_lo[3], int box_hi[3]) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) { mxh_set_error("mxh_partition: bad rank"); return 1; }
+  int pg[3];
+  procGridOf(n, nranks, pg);
+  int factor = 1;
+  for (int i = 2; i >= 0; --i) {                                  // src/MxGrid.cpp:171-193
+    const int stdRes = int(std::floor(double(n[i]) / double(pg[i]) + 0.5));
+    const int proci = (rank / factor) % pg[i];
+    box_lo[i] = proci * stdRes;
+    box_hi[i] = (proci == pg[i] - 1) ? n[i] + 1 : box_lo[i] + stdRes;
+    factor *= pg[i];
+    proc_grid[i] = pg[i];
+  }
+  return 0;
+}
+
+extern "C" int mxh_owner_of_cell(const int n[3], const int pg[3], const int cell[3]) {
+  int pid = 0, factor = 1;
+  for (int i = 2; i >= 0; --i) {
+    const int stdRes = int(std::floor(double(n[i]) / double(pg[i]) + 0.5));
+    int proci = stdRes > 0 ? cell[i] / stdRes : 0;
+    if (proci > pg[i] - 1) proci = pg[i] - 1;
+    pid += proci * factor;
+    factor *= pg[i];
+  }
+  return pid;
+}
+
+extern "C" int mxh_sim_dist_op(mxh_sim* s, const char* name, double shift, int64_t* nrows, int64_t* nnz,
+                               const int64_t** rowptr, const int64_t** col_gids, const double** vals,
+                               const int64_t** row_gids, int64_t* n_owned_cols,
+                               const int64_t** col_field_owned_gids, int* col_ncomp) {
+  try {
+    const std::string nm(name);
+    const mx::YeeAssembler<double>& a = *s->asmb;
+    const mx::YeeField &B = a.bfield(), &E = a.efield(), &P = a.psifield();
+    const mx::YeeField* rowF = &B; const mx::YeeField* colF = &B;
+    if (nm == "scaLapl" || nm == "dmVInv") { rowF = &P; colF = &P; }
+    else if (nm == "divB") { rowF = &P; colF = &B; }
+    else if (nm == "gradPsi") { rowF = &B; colF = &P; }
+    else if (nm == "curlE") { rowF = &B; colF = &E; }
+    else if (nm == "curlB") { rowF = &E; colF = &B; }
+    else if (nm == "dmL") { rowF = &E; colF = &E; }
+    const mx::Csr<double>* m;
+    if (nm == "shifted") m = &mxh_sim_shifted_matrix(s, shift);
+    else {
+      auto it = s->ops.find(nm);
+      if (it == s->ops.end()) throw std::runtime_error("MxEMOps::getOp: operator '" + nm + "' not found.");
+      m = &it->second;
+    }
+    char key[96];
+    std::snprintf(key, sizeof(key), "%s@%.17g", name, nm == "shifted" ? shift : 0.0);
+    mxh_sim::DistOp& d = s->dist[key];
+    mx::Csr<double> o = a.ownedRows(*m, *rowF);
+    d.rowptr = o.rowptr;
+    d.vals = o.val;
+    d.colgid.resize(o.col.size());
+    for (size_t q = 0; q < o.col.size(); ++q) d.colgid[q] = colF->gids[o.col[q]];
+    d.rowgid = a.ownedGids(*rowF);
+    d.colowned = a.ownedGids(*colF);
+    if (nrows) *nrows = o.nrows;
+    if (nnz) *nnz = o.nnz();
+    if (rowptr) *rowptr = d.rowptr.data();
+    if (col_gids) *col_gids = d.colgid.data();
+    if (vals) *vals = d.vals.data();
+    if (row_gids) *row_gids = d.rowgid.data();
+    if (n_owned_cols) *n_owned_cols = (int64_t)d.colowned.size();
+    if (col_field_owned_gids) *col_field_owned_gids = d.colowned.data();
+    if (col_ncomp) *col_ncomp = colF->ncomp;
+    return 0;
+  } catch (const std::exception& e) {
+    mxh_set_error(e.what());
+    return 1;
+  }
+}

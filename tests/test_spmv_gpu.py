@@ -197,3 +197,42 @@ def test_pipelined_kernel_ragged(ctx, rng):
         mask = np.ones(n, bool); mask[3] = False
         assert np.array_equal(got[mask], want[mask])
         assert abs(got[3] - want[3]) <= 1e-12 * np.abs(m[3].data).sum()
+
+
+def test_halo_exchange_on_a_one_rank_communicator(built, oracle_pillbox12, rng):
+    """C1 on one GPU: a 1-rank RCCL communicator sends to itself.  Part of the columns is re-routed
+    through ghost slots fed by the halo plan (pack kernel -> ncclSend/ncclRecv -> [owned | ghosts]);
+    the product must equal the plain one bit for bit."""
+    import ctypes as C
+    from maxwell_amd import _lib
+    _, o = oracle_pillbox12
+    m = yee.shifted(o["vecLapl"], o["mRhs"], 1.97).tocsr()
+    n = m.shape[0]
+    ghosted = np.nonzero(np.arange(n) % 5 == 0)[0]                # owned entries that also travel as ghosts
+    slot = -np.ones(n, dtype=np.int64); slot[ghosted] = n + np.arange(len(ghosted))
+    cols = m.indices.astype(np.int64).copy()
+    reroute = (slot[cols] >= 0) & (rng.uniform(0, 1, len(cols)) < 0.7)
+    cols[reroute] = slot[cols[reroute]]
+    rowptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+    colidx = np.ascontiguousarray(cols, dtype=np.int32)
+    vals = np.ascontiguousarray(m.data)
+    neigh = np.array([0], dtype=np.int32)
+    off = np.array([0, len(ghosted)], dtype=np.int64)
+    send_idx = np.ascontiguousarray(ghosted, dtype=np.int64)
+    plan = _lib.HaloPlan(1, neigh.ctypes.data_as(C.POINTER(C.c_int)), off.ctypes.data_as(_lib.c_i64p),
+                         send_idx.ctypes.data_as(_lib.c_i64p), off.ctypes.data_as(_lib.c_i64p))
+    ctx1 = mx.Ctx(0, 0, 1, mx.Ctx.unique_id())
+    try:
+        A = mx.CsrMatrix(ctx1, n, n, rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p),
+                         vals.ctypes.data_as(C.c_void_p), False, nghost=len(ghosted), plan=C.byref(plan))
+        x = rng.uniform(-1, 1, (n, 2))
+        X = mx.MultiVec.from_numpy(ctx1, x); Y = mx.MultiVec(ctx1, n, 2)
+        A.apply(X, Y)
+        assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+        # the collectives of C2 on the same communicator
+        assert np.abs(X.norm2() - np.linalg.norm(x, axis=0)).max() < 1e-12
+        ctx1.barrier()
+        for obj in (A, X, Y):
+            obj.close()
+    finally:
+        ctx1.close()
