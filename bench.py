@@ -36,11 +36,13 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--n", type=int, default=256, help="Yee cells per side (per GPU)")
+    p.add_argument("--cells", dest="n", type=int, default=256, help="Yee cells per side (per GPU)")
     p.add_argument("--k", type=int, default=1, help="vectors in the block (SpMM when > 1)")
     p.add_argument("--kernel", type=lambda v: int(v, 0), default=-1, help="SpMV kernel variant code (default: library default)")
-    p.add_argument("--eig-n", type=int, default=96, help="grid of the eigenpairs/s measurement (0 = skip)")
+    p.add_argument("--eig-n", type=int, default=128, help="grid of the eigenpairs/s measurement (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
+    p.add_argument("--dist-selftest", action="store_true",
+                   help="run the N > 1 code path (torch.distributed + RCCL ctx + box assembly + halo plan) on 1 rank")
     return p.parse_args()
 
 
@@ -73,6 +75,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("WARNING: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if world > 1 or args.dist_selftest:
+        # torch bundles its own ROCm runtime libraries with the same SONAMEs as /opt/rocm's: whichever
+        # is loaded first serves the whole process.  Import torch BEFORE libmxg so that both run on one
+        # consistent set (the usual situation of a torch extension); N = 1 never imports torch.
+        import torch  # noqa: F401
     from maxwell_amd import _env
     _env.set_omp_threads()                     # the box's CPU share, not its 256 visible threads
     import __graft_entry__ as entry
@@ -82,22 +89,26 @@ def main():
 
     dist = None
     uid = None
-    if world > 1:
+    if world > 1 or args.dist_selftest:
+        # Control plane only: rendezvous, the RCCL unique id, setup-time object collectives and the
+        # final max/sum of the timings go over gloo on the CPU.  The data path (halo exchange,
+        # inner-product all-reduce) is RCCL inside libmxg.  torch never touches the GPU here, so
+        # the process holds exactly one HIP/RCCL runtime (the ROCm one libmxg links).
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dist.barrier()
-        buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            buf = torch.tensor(list(mx.Ctx.unique_id()), dtype=torch.uint8, device="cuda")
-        dist.broadcast(buf, 0)
-        uid = bytes(buf.cpu().tolist())
+        if "MASTER_ADDR" not in os.environ:     # selftest without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("gloo")
+        box = [mx.Ctx.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    if os.environ.get("MXG_SHARE_GPU"):        # rehearsal of N ranks on a 1-GPU box (RCCL may refuse duplicates)
+        local = 0
     ctx = mx.Ctx(local, rank, world, uid)
 
     shift = 0.05 * (2.0 * np.pi) ** 2          # src/mx.py:711-712 default for the unit box
     t0 = time.perf_counter()
-    if world == 1:
+    if world == 1 and not args.dist_selftest:
         sim = mx.Sim.pillbox(args.n)
         A = sim.to_device(ctx, "vecLapl", shift=shift)
         workload = "pillbox %d^3 Yee cells, vecLapl - shift*dmA (example/pillbox.py geometry)" % args.n
@@ -115,23 +126,24 @@ def main():
     X.random(12345)
     for _ in range(args.warmup):
         A.apply(X, Y)
-    ctx.sync()
+    ctx.barrier()                              # stream sync (+ RCCL all-reduce across ranks)
     if dist: dist.barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
         A.apply(X, Y)
-    ev_ms = ctx.timer_stop()                   # HIP events on the ctx stream (includes ctx.sync)
+    ev_ms = ctx.timer_stop()                   # HIP events on the ctx stream (waits for the stream)
+    ctx.barrier()
     if dist: dist.barrier()
     wall = time.perf_counter() - t0
     alg = A.apply_bytes(args.k)
     rows, nnz = A.nrows, A.nnz
     if dist:
         import torch
-        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = t.tolist()
-        s = torch.tensor([alg, rows, nnz], dtype=torch.float64, device="cuda")
+        s = torch.tensor([alg, rows, nnz], dtype=torch.float64)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         alg, rows, nnz = [int(v) for v in s.tolist()]
     ms_per_step = wall * 1e3 / args.steps
@@ -154,19 +166,24 @@ def main():
                      "algorithmic_bytes_per_launch": alg // world,
                      "note": "achieved = nnz*12 + rows*(8+8k) + cols*8k bytes / HIP-event time per launch"},
     }
-    if rank == 0 and args.cpu_seconds > 0 and world == 1:
+    if rank == 0 and args.cpu_seconds > 0 and world == 1 and not args.dist_selftest:
         out["cpu_baseline"] = cpu_baseline(sim, shift, A.nrows, alg, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if args.eig_n > 0 and world == 1:
+    if args.eig_n > 0 and world == 1 and not args.dist_selftest:
         try:
             out["eigen"] = eigen_bench(mx, ctx, args.eig_n)
         except Exception as e:   # the SpMV line must still print
             out["eigen"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    # orderly teardown: device objects, then the RCCL communicator, then the control plane
+    for obj in (X, Y, A):
+        obj.close()
     if dist:
         dist.barrier()
+    ctx.close()
+    if dist:
         dist.destroy_process_group()
 
 
