@@ -81,7 +81,9 @@ def main():
         # consistent set (the usual situation of a torch extension); N = 1 never imports torch.
         import torch  # noqa: F401
     from maxwell_amd import _env
-    _env.set_omp_threads()                     # the box's CPU share, not its 256 visible threads
+    if world > 1:
+        os.environ.pop("OMP_NUM_THREADS", None)   # torchrun pins it to 1; the host assembly wants its share
+    _env.set_omp_threads()                     # the box's CPU share / ranks on this node, not all visible threads
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
