@@ -16,7 +16,7 @@ def host_threads(default_cap=64):
 
 
 def set_omp_threads():
-    """Must run before libgomp is loaded (i.e. before libmxhost / liboracle are opened)."""
+    """Must run before libgomp is loaded (i.e. before any OpenMP library of this repo is opened)."""
     if "OMP_NUM_THREADS" not in os.environ:
         ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)   # one process per GPU on this node
         os.environ["OMP_NUM_THREADS"] = str(max(1, min(32, host_threads() // max(ranks_here, 1))))
