@@ -148,13 +148,29 @@ int mxg_mv_trans_mv(double alpha_re, double alpha_im, const mxg_mv* A, const mxg
  * inner Krylov solves  (replaces AztecOO::recursiveIterate + TrueResidual loop,
  *                       src/MxMagWaveOp.cpp:874-885,907-913; options :326-353)
  * ---------------------------------------------------------------------------------------- */
+/* Multigrid preconditioner (K11): stands in for ML's smoothed-aggregation AMG
+ * (src/MxMagWaveOp.cpp:425-449,524-531) with SpMV-only ingredients.  The caller supplies the
+ * hierarchy (level operators A[0..nlevels), prolongations P[l]: n_l x n_{l+1}, restrictions
+ * R[l]: n_{l+1} x n_l); one application is a V(pre, post) cycle with damped-Jacobi smoothing,
+ * `coarse_sweeps` Jacobi sweeps on the coarsest level and the coarse correction scaled by
+ * `coarse_scale` (1.8-2 compensates the under-correction of piecewise-constant aggregation).
+ * The cycle is a fixed symmetric positive operator, so it is a legal CG preconditioner. */
+typedef struct mxg_mg mxg_mg;
+int mxg_mg_create(mxg_ctx* ctx, int nlevels, mxg_csr* const* A, mxg_csr* const* P, mxg_csr* const* R,
+                  int pre_sweeps, int post_sweeps, int coarse_sweeps, double omega, double coarse_scale,
+                  mxg_mg** out);
+int mxg_mg_destroy(mxg_mg* mg);
+/* z = M^-1 r (one column), one V-cycle */
+int mxg_mg_apply(mxg_ctx* ctx, mxg_mg* mg, const mxg_mv* r, mxg_mv* z);
+
 typedef struct mxg_solve_opts {
   double tol;          /* unscaled true-residual 2-norm target (AZ_noscaled, :346,352) */
   int restart;         /* Krylov subspace (AZ_kspace, "linear solver : basis") */
   int max_iters;       /* total iteration cap; 0 = library default */
-  int precond;         /* 0 none, 1 Jacobi (diagonal), 2 Chebyshev polynomial of A */
-  int cheb_degree;     /* polynomial degree when precond == 2 */
-  double lmin, lmax;   /* spectrum bounds for Chebyshev; lmax <= 0: estimate by power iteration */
+  int precond;         /* 0 none, 1 Jacobi (diagonal), 3 multigrid V-cycle (`mg`) */
+  int cheb_degree;     /* reserved */
+  double lmin, lmax;   /* reserved */
+  mxg_mg* mg;          /* hierarchy for precond == 3 (not owned) */
 } mxg_solve_opts;
 
 typedef struct mxg_solve_info {

@@ -74,6 +74,21 @@ int mxh_sim_used_mask(mxh_sim* s, int64_t* n, const double** mask);
 double mxh_sim_setup_seconds(const mxh_sim* s);
 
 /* ---------------------------------------------------------------------------------------
+ * Multigrid preconditioner setup (K11): geometric aggregation on the Yee lattice, Galerkin coarse
+ * operators on the host, V-cycle on the GPU (mxg_mg_*).  Replaces the ML hierarchy of
+ * src/MxMagWaveOp.cpp:425-449,524-531 ("linear solver : prec type" = amg).
+ * ------------------------------------------------------------------------------------- */
+typedef struct mxh_mg mxh_mg;
+/* op: "shifted" (vecLapl - shift*mRhs, B field) or "scaLapl" (Psi field) */
+int mxh_mg_create(mxg_ctx* ctx, mxh_sim* sim, const char* op, double shift, int64_t min_coarse,
+                  int max_levels, int sweeps, int coarse_sweeps, double omega, double coarse_scale,
+                  mxh_mg** out);
+int mxh_mg_destroy(mxh_mg* mg);
+mxg_mg* mxh_mg_handle(mxh_mg* mg);          /* the device V-cycle (for mxg_solve_opts.mg) */
+mxg_csr* mxh_mg_fine_matrix(mxh_mg* mg);    /* level-0 operator on the device */
+int mxh_mg_level_sizes(mxh_mg* mg, int64_t* rows, int64_t* nnz, int* nlevels);   /* arrays of >= 16 */
+
+/* ---------------------------------------------------------------------------------------
  * Eigen-driver: MxSolver + MxMagWaveOp on one GPU context
  * (src/MxSolver.cpp:24-94 ctor, :100-239 solve; src/MxMagWaveOp.cpp:826-943 Apply)
  * ------------------------------------------------------------------------------------- */

@@ -18,7 +18,7 @@ INCLUDE = os.path.join(ROOT, "include")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 DEVICE_SOURCES = ["mxg_ctx.hip", "mxg_mv.hip", "mxg_csr.hip", "mxg_solve.hip"]
-HOST_SOURCES = ["mx_geometry.cpp", "mx_yee.cpp", "mxh_sim.cpp", "mxh_solver.cpp"]
+HOST_SOURCES = ["mx_geometry.cpp", "mx_yee.cpp", "mxh_sim.cpp", "mxh_mg.cpp", "mxh_solver.cpp"]
 
 
 def _digest(sources, extra=""):

@@ -24,7 +24,7 @@ class HaloPlan(C.Structure):
 class SolveOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("restart", C.c_int), ("max_iters", C.c_int),
                 ("precond", C.c_int), ("cheb_degree", C.c_int),
-                ("lmin", C.c_double), ("lmax", C.c_double)]
+                ("lmin", C.c_double), ("lmax", C.c_double), ("mg", C.c_void_p)]
 
 
 class SolveInfo(C.Structure):
@@ -79,6 +79,10 @@ MXG_SIGNATURES = {
     "mxg_mv_times_mat": (C.c_int, [C.c_double, C.c_double, vp, vp, C.c_int, C.c_int, C.c_int,
                                    C.c_double, C.c_double, vp]),
     "mxg_mv_trans_mv": (C.c_int, [C.c_double, C.c_double, vp, vp, vp, C.c_int]),
+    "mxg_mg_create": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
+                                C.c_double, C.c_double, C.POINTER(vp)]),
+    "mxg_mg_destroy": (C.c_int, [vp]),
+    "mxg_mg_apply": (C.c_int, [vp, vp, vp, vp]),
     "mxg_solve_cg": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "mxg_solve_gmres": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
 }
@@ -104,6 +108,12 @@ MXH_SIGNATURES = {
     "mxh_sim_map": (C.c_int, [vp, C.c_char_p, c_i64p, C.POINTER(c_i64p)]),
     "mxh_sim_used_mask": (C.c_int, [vp, c_i64p, C.POINTER(c_dp)]),
     "mxh_sim_setup_seconds": (C.c_double, [vp]),
+    "mxh_mg_create": (C.c_int, [vp, vp, C.c_char_p, C.c_double, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double,
+                                C.c_double, C.POINTER(vp)]),
+    "mxh_mg_destroy": (C.c_int, [vp]),
+    "mxh_mg_handle": (vp, [vp]),
+    "mxh_mg_fine_matrix": (vp, [vp]),
+    "mxh_mg_level_sizes": (C.c_int, [vp, c_i64p, c_i64p, c_ip]),
     "mxh_solver_default_params": (None, [C.POINTER(SolverParamsC)]),
     "mxh_solver_create": (C.c_int, [vp, vp, C.POINTER(SolverParamsC), C.POINTER(vp)]),
     "mxh_solver_destroy": (C.c_int, [vp]),

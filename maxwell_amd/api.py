@@ -244,8 +244,9 @@ class CsrMatrix:
     def set_kernel(self, which):
         self.lib.mxg_csr_set_kernel(self.h, which)
 
-    def solve(self, b, x, method="cg", tol=1e-6, restart=40, max_iters=0, precond="none"):
-        opts = _lib.SolveOpts(tol, restart, max_iters, {"none": 0, "jacobi": 1}[precond], 0, 0.0, 0.0)
+    def solve(self, b, x, method="cg", tol=1e-6, restart=40, max_iters=0, precond="none", mg=None):
+        opts = _lib.SolveOpts(tol, restart, max_iters, {"none": 0, "jacobi": 1, "mg": 3}[precond], 0, 0.0, 0.0,
+                              mg.handle if mg is not None else None)
         info = _lib.SolveInfo()
         fn = self.lib.mxg_solve_cg if method == "cg" else self.lib.mxg_solve_gmres
         _chk(fn(self.ctx.h, self.h, b.h, x.h, C.byref(opts), C.byref(info)), self.lib)
@@ -333,6 +334,50 @@ class Sim:
     def close(self):
         if self.h:
             self.lib.mxh_sim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Multigrid:
+    """Aggregation multigrid for the shifted vector Laplacian ("shifted") or the scalar Laplacian
+    ("scaLapl") of a Sim: hierarchy built on the host, V-cycle on the GPU."""
+
+    def __init__(self, ctx, sim, op="shifted", shift=0.0, min_coarse=2000, max_levels=10, sweeps=2,
+                 coarse_sweeps=30, omega=0.7, coarse_scale=1.9):
+        self.lib = _lib.load_mxhost()
+        self.ctx, self.sim = ctx, sim
+        h = C.c_void_p()
+        _chk(self.lib.mxh_mg_create(ctx.h, sim.h, op.encode(), float(shift), int(min_coarse), int(max_levels),
+                                    int(sweeps), int(coarse_sweeps), float(omega), float(coarse_scale),
+                                    C.byref(h)), self.lib, "mxh")
+        self.h = h
+        self.handle = C.c_void_p(self.lib.mxh_mg_handle(h))
+        rows, nnz, nl = (C.c_int64 * 16)(), (C.c_int64 * 16)(), C.c_int()
+        self.lib.mxh_mg_level_sizes(h, rows, nnz, C.byref(nl))
+        self.levels = [(rows[i], nnz[i]) for i in range(nl.value)]
+
+    def fine_matrix(self):
+        """Borrowed CsrMatrix wrapper of the level-0 operator (owned by this object)."""
+        m = CsrMatrix.__new__(CsrMatrix)
+        m.ctx, m.lib = self.ctx, self.ctx.lib
+        m.h = C.c_void_p(self.lib.mxh_mg_fine_matrix(self.h))
+        m.nrows = m.ncols = self.levels[0][0]
+        m.nnz, m.is_complex = self.levels[0][1], False
+        m.close = lambda: None
+        m._owner = self
+        return m
+
+    def apply(self, r, z):
+        _chk(self.ctx.lib.mxg_mg_apply(self.ctx.h, self.handle, r.h, z.h), self.ctx.lib)
+
+    def close(self):
+        if self.h:
+            self.lib.mxh_mg_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -482,10 +482,13 @@ struct RgCfg {
 typedef RgCfg<256, 2048> RgCfgA;   // 16 KiB values + 8 KiB columns per block
 typedef RgCfg<256, 3072> RgCfgB;   // rows up to 12 nnz stay at 256 rows per block
 
-template <typename CFG, int CH>
+// DOT: additionally emit partial[b] = sum over the block's rows of y[row] * xdot[row] (the p.Ap of
+// CG fused into the product; one value per block, combined in block order by k_sum_partials)
+template <typename CFG, int CH, bool DOT = false>
 __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
     const BlkDesc* __restrict__ desc, long long nblocks, const long long* __restrict__ rowptr,
-    const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y) {
+    const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y,
+    const double* __restrict__ xdot = nullptr, double* __restrict__ partial = nullptr) {
   constexpr int SB = CFG::SBLK, EPT = CFG::EPT;
   __shared__ double sval[CFG::NNZ_BLK];
   __shared__ int scol[CFG::NNZ_BLK];
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
         double tr = 0.0;
         for (int q = 0; q < SB; ++q) tr += sval[q];
         Y.col(j)[d.r0] = tr;
+        if (DOT && j == 0) partial[b] = tr * xdot[d.r0];
       }
     }
     return;
@@ -546,7 +550,34 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
         if (q0 + i < o1) sum += v[i] * xv[i];
     }
     if ((int)threadIdx.x < d.nr) __builtin_nontemporal_store(sum, Y.col(j) + d.r0 + threadIdx.x);
+    if (DOT && j == 0) {
+      double part = (int)threadIdx.x < d.nr ? sum * xdot[d.r0 + threadIdx.x] : 0.0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+      __syncthreads();                       // every row sum is done with sval[]
+      if ((threadIdx.x & 63) == 0) sval[threadIdx.x >> 6] = part;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < SB / 64; ++w) tot += sval[w];
+        partial[b] = tot;
+      }
+    }
   }
+}
+
+// out[0] = sum of partial[0..n) in index order (single workgroup, fixed tree: reproducible)
+__global__ void k_sum_partials(const double* __restrict__ partial, long long n, double* __restrict__ out) {
+  __shared__ double lds[1024];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 1024) s += partial[i];
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) lds[threadIdx.x] += lds[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = lds[0];
 }
 
 // Reference-style kernel for A/B experiments: one row per group of G lanes, shuffle reduction.
@@ -707,11 +738,13 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
 
 extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (!a) return 0;
+  if (!mxg_ctx_alive(a->ctx)) { delete a; return 0; }   // context already gone
   hipSetDevice(a->ctx->device);
   hipStreamSynchronize(a->ctx->stream);
   hipFree(a->d_rowptr); hipFree(a->d_colidx); hipFree(a->d_vals); hipFree(a->d_rowblk);
   hipFree(a->d_diag);
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
+  if (a->d_dotpartial) hipFree(a->d_dotpartial);
   if (a->d_xwdesc) hipFree(a->d_xwdesc);
   if (a->d_lcol) hipFree(a->d_lcol);
   if (a->d_send_idx) hipFree(a->d_send_idx);
@@ -867,6 +900,7 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
     desc[b] = d;
   }
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
+  if (a->d_dotpartial) { hipFree(a->d_dotpartial); a->d_dotpartial = nullptr; }
   MXG_HIP(hipMalloc(&a->d_blkdesc, sizeof(BlkDesc) * std::max<size_t>(desc.size(), 1)));
   if (!desc.empty())
     MXG_HIP(hipMemcpyAsync(a->d_blkdesc, desc.data(), sizeof(BlkDesc) * desc.size(),
@@ -1058,6 +1092,28 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
     else MXG_LAUNCH(CfgDefault);
 #undef MXG_LAUNCH
   }
+  MXG_HIP(hipGetLastError());
+  return 0;
+}
+
+// y = A x and d_out[0] = x . y in one pass over the matrix (real, one column, row-gather geometry).
+// x . y uses the owned rows only; the caller all-reduces d_out across ranks if needed.
+int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out) {
+  MXG_CHECK(!a->is_complex && x->k == 1 && y->k == 1 && a->nrows == a->ncols_owned,
+            "mxg_dev_csr_apply_dot: real square single-column case only");
+  MXG_CHECK(a->pipe_geo == 10 && a->npipe > 0, "mxg_dev_csr_apply_dot: row-gather descriptors missing");
+  MvDesc X = x->desc();
+  const MvDesc Y = y->desc();
+  if (a->nghost > 0 || a->nneigh > 0) MXG_TRY(halo_exchange(c, a, x, &X));
+  if (!a->d_dotpartial) MXG_HIP(hipMalloc(&a->d_dotpartial, sizeof(double) * a->npipe));
+  const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+  const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((k_spmv_rowgather<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,
+                     (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr,
+                     a->d_colidx, a->d_vals, X, Y, (const double*)x->colptr(0), a->d_dotpartial);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, (const double*)a->d_dotpartial,
+                     (long long)a->npipe, d_out);
   MXG_HIP(hipGetLastError());
   return 0;
 }

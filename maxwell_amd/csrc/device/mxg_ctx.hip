@@ -2,10 +2,21 @@
 // Replaces MxComm / Epetra_MpiComm (reference src/MxComm.hpp:14-37): one process per GPU,
 // collectives go through RCCL on the ctx stream.
 #include <cstdarg>
+#include <mutex>
+#include <set>
 
 #include "mxg_internal.h"
 
 static thread_local std::string g_last_error;
+
+// live contexts: destroy calls that arrive after their context is gone (interpreter shutdown
+// destroys objects in arbitrary order) must not touch the device through a dangling pointer
+static std::mutex g_ctx_mutex;
+static std::set<const mxg_ctx*> g_live_ctx;
+bool mxg_ctx_alive(const mxg_ctx* c) {
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  return g_live_ctx.count(c) != 0;
+}
 
 void mxg_set_error(const char* fmt, ...) {
   char buf[1024];
@@ -55,12 +66,14 @@ extern "C" int mxg_ctx_create(int device, int rank, int nranks, const void* nccl
     MXG_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
   }
   if (mxg_ctx_reserve_reduce(c, 64) != 0) return 1;
+  { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_live_ctx.insert(c); }
   *out = c;
   return 0;
 }
 
 extern "C" int mxg_ctx_destroy(mxg_ctx* c) {
-  if (!c) return 0;
+  if (!c || !mxg_ctx_alive(c)) return 0;
+  { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_live_ctx.erase(c); }
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);

@@ -125,6 +125,7 @@ struct mxg_csr {
   void* d_blkdesc = nullptr;
   int64_t npipe = 0;
   int pipe_geo = -1;
+  double* d_dotpartial = nullptr;   // per-block partials of the fused SpMV + dot
   // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
   void* d_xwdesc = nullptr;
   unsigned short* d_lcol = nullptr;
@@ -144,6 +145,8 @@ struct mxg_csr {
   int halo_kcap = 0;
 };
 
+bool mxg_ctx_alive(const mxg_ctx* c);
+
 // reductions / workspace helpers (mxg_ctx.hip)
 int mxg_ctx_reserve_reduce(mxg_ctx* ctx, size_t width);
 int mxg_ctx_reserve_small(mxg_ctx* ctx, size_t doubles);
@@ -154,6 +157,9 @@ int mxg_ctx_finish_reduce(mxg_ctx* ctx, size_t width, double* host_out);
 // device-side entry points used across translation units (results stay on device)
 // d_out[j] = sum_i conj(A_j[i]) * B_j[i]; complex results interleaved. No all-reduce, no sync.
 int mxg_dev_dot(mxg_ctx* ctx, const MvDesc& A, const MvDesc& B, double* d_out);
+
+// y = A x with the p.Ap of CG fused in (mxg_csr.hip); d_out is a device scalar
+int mxg_dev_csr_apply_dot(mxg_ctx* ctx, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out);
 
 inline int mxg_grid_for(int64_t n, int block, int per_thread, int cap) {
   int64_t g = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);

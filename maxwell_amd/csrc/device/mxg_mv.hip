@@ -405,6 +405,7 @@ extern "C" int mxg_mv_clone(const mxg_mv* s, const int* cols, int n, mxg_mv** ou
 
 extern "C" int mxg_mv_destroy(mxg_mv* v) {
   if (!v) return 0;
+  if (!mxg_ctx_alive(v->ctx)) { delete v; return 0; }   // context already gone: nothing to release safely
   hipSetDevice(v->ctx->device);
   hipStreamSynchronize(v->ctx->stream);
   if (v->owner && v->base) hipFree(v->base);

@@ -9,6 +9,7 @@
 // reductions instead of j.  The ILU / AMG preconditioners of the reference are Trilinos
 // packages and are replaced by SpMV-only ones (Jacobi, Chebyshev polynomial): they change the
 // iteration count, not the converged answer.
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <vector>
@@ -63,6 +64,10 @@ int apply_prec(mxg_ctx* c, const mxg_csr* A, const mxg_solve_opts* o, const mxg_
     MXG_HIP(hipGetLastError());
     return 0;
   }
+  if (o->precond == 3) {
+    MXG_CHECK(o->mg != nullptr, "precond == 3 needs opts->mg");
+    return mxg_mg_apply(c, o->mg, r, z);
+  }
   return mxg_mv_copy(z, r);
 }
 
@@ -71,6 +76,272 @@ int true_residual(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, const mxg_mv* x
   MXG_TRY(mxg_csr_apply(c, A, x, r));
   MXG_TRY(mxg_mv_axpby(1.0, 0.0, b, -1.0, 0.0, r));   // r = b - A x
   return mxg_mv_norm2(r, nrm);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Fused CG (real scalars, Jacobi or no preconditioner): three passes per iteration and no host
+// round trip inside a chunk of iterations.
+//   1. q = A p with p.q folded into the SpMV          (mxg_dev_csr_apply_dot)
+//   2. x += a p, r -= a q, z = D^-1 r, r.z and r.r     (k_cg_update; a = rz / pq read on the device)
+//   3. p = z + b p                                     (k_cg_dir;   b = rz_new / rz read on the device)
+// All scalars live in ctx->d_result; across ranks they are all-reduced in place on the stream.
+// Every CHUNK iterations r.r comes to the host for the convergence test (unscaled 2-norm).
+// ------------------------------------------------------------------------------------------
+constexpr int CGB = 256;
+enum { S_RZ0 = 0, S_RZ1 = 1, S_PQ = 2, S_RR = 3 };
+
+__global__ void k_cg_update(long long n, double* __restrict__ x, double* __restrict__ r,
+                            const double* __restrict__ p, const double* __restrict__ q,
+                            double* __restrict__ z, const double* __restrict__ diag,
+                            const double* __restrict__ scal, int irz, double* __restrict__ partial) {
+  __shared__ double lds[2][CGB / 64];
+  const double pq = scal[S_PQ];
+  const double alpha = pq != 0.0 ? scal[irz] / pq : 0.0;
+  double srz = 0.0, srr = 0.0;
+  const long long stride = (long long)gridDim.x * CGB;
+  for (long long i = (long long)blockIdx.x * CGB + threadIdx.x; i < n; i += stride) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    double zi = ri;
+    if (diag) { const double d = diag[i]; zi = d != 0.0 ? ri / d : 0.0; }
+    z[i] = zi;
+    srz += ri * zi;
+    srr += ri * ri;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { srz += __shfl_down(srz, off, 64); srr += __shfl_down(srr, off, 64); }
+  if ((threadIdx.x & 63) == 0) { lds[0][threadIdx.x >> 6] = srz; lds[1][threadIdx.x >> 6] = srr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < CGB / 64; ++w) { a += lds[0][w]; b += lds[1][w]; }
+    partial[blockIdx.x] = a;
+    partial[MXG_MAX_RED_BLOCKS + blockIdx.x] = b;
+  }
+}
+
+__global__ void k_cg_reduce2(const double* __restrict__ partial, int nblocks, double* __restrict__ scal,
+                             int irz_new) {
+  __shared__ double lds[CGB];
+  const double* p = partial + (size_t)blockIdx.x * MXG_MAX_RED_BLOCKS;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += CGB) s += p[i];
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = CGB / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) lds[threadIdx.x] += lds[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scal[blockIdx.x == 0 ? irz_new : S_RR] = lds[0];
+}
+
+__global__ void k_cg_dir(long long n, double* __restrict__ p, const double* __restrict__ z,
+                         const double* __restrict__ scal, int irz_old, int irz_new) {
+  const double den = scal[irz_old];
+  const double beta = den != 0.0 ? scal[irz_new] / den : 0.0;
+  const long long stride = (long long)gridDim.x * CGB;
+  for (long long i = (long long)blockIdx.x * CGB + threadIdx.x; i < n; i += stride) p[i] = z[i] + beta * p[i];
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Aggregation multigrid V-cycle (K11 replacement, SpMV-only): every ingredient is a CSR product
+// (level operator, prolongation, restriction) or a fused vector kernel.
+// ------------------------------------------------------------------------------------------
+}  // namespace
+
+struct mxg_mg {
+  mxg_ctx* ctx = nullptr;
+  int nlevels = 0;
+  std::vector<mxg_csr*> A, P, R;
+  std::vector<mxg_mv*> r, z, t;       // per level: right-hand side, correction, scratch
+  int pre = 2, post = 2, coarse = 20;
+  double omega = 0.7, cscale = 1.9;
+};
+
+namespace {
+
+// z = omega * D^-1 r   (first sweep from a zero guess)
+__global__ void k_jac_first(long long n, const double* __restrict__ diag, double omega,
+                            const double* __restrict__ r, double* __restrict__ z) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double d = diag[i];
+    z[i] = d != 0.0 ? omega * r[i] / d : 0.0;
+  }
+}
+// z += omega * D^-1 (r - t), t = A z
+__global__ void k_jac_step(long long n, const double* __restrict__ diag, double omega,
+                           const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double d = diag[i];
+    if (d != 0.0) z[i] += omega * (r[i] - t[i]) / d;
+  }
+}
+// t = r - t
+__global__ void k_resid(long long n, const double* __restrict__ r, double* __restrict__ t) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) t[i] = r[i] - t[i];
+}
+// z += s * t
+__global__ void k_axpy1(long long n, double s, const double* __restrict__ t, double* __restrict__ z) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) z[i] += s * t[i];
+}
+
+int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
+  mxg_ctx* c = mg->ctx;
+  mxg_csr* A = mg->A[l];
+  const long long n = A->nrows;
+  const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
+  for (int s = 0; s < sweeps; ++s) {
+    if (s == 0 && zero_guess) {
+      hipLaunchKernelGGL(k_jac_first, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag,
+                         mg->omega, (const double*)mg->r[l]->colptr(0), mg->z[l]->colptr(0));
+    } else {
+      MXG_TRY(mxg_csr_apply(c, A, mg->z[l], mg->t[l]));
+      hipLaunchKernelGGL(k_jac_step, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag,
+                         mg->omega, (const double*)mg->r[l]->colptr(0), (const double*)mg->t[l]->colptr(0),
+                         mg->z[l]->colptr(0));
+    }
+  }
+  MXG_HIP(hipGetLastError());
+  return 0;
+}
+
+int mg_cycle(mxg_mg* mg, int l) {
+  mxg_ctx* c = mg->ctx;
+  if (l == mg->nlevels - 1) return mg_smooth(mg, l, mg->coarse, true);
+  const long long n = mg->A[l]->nrows;
+  const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
+  MXG_TRY(mg_smooth(mg, l, mg->pre, true));
+  MXG_TRY(mxg_csr_apply(c, mg->A[l], mg->z[l], mg->t[l]));                       // t = A z
+  hipLaunchKernelGGL(k_resid, dim3(grid), dim3(256), 0, c->stream, n, (const double*)mg->r[l]->colptr(0),
+                     mg->t[l]->colptr(0));                                        // t = r - A z
+  MXG_TRY(mxg_csr_apply(c, mg->R[l], mg->t[l], mg->r[l + 1]));                    // restrict
+  MXG_TRY(mg_cycle(mg, l + 1));
+  MXG_TRY(mxg_csr_apply(c, mg->P[l], mg->z[l + 1], mg->t[l]));                    // prolong
+  hipLaunchKernelGGL(k_axpy1, dim3(grid), dim3(256), 0, c->stream, n, mg->cscale,
+                     (const double*)mg->t[l]->colptr(0), mg->z[l]->colptr(0));
+  MXG_HIP(hipGetLastError());
+  return mg_smooth(mg, l, mg->post, false);
+}
+
+}  // namespace
+
+extern "C" int mxg_mg_create(mxg_ctx* c, int nlevels, mxg_csr* const* A, mxg_csr* const* P,
+                             mxg_csr* const* R, int pre, int post, int coarse, double omega,
+                             double cscale, mxg_mg** out) {
+  MXG_CHECK(c && A && out && nlevels >= 1, "mxg_mg_create: bad argument");
+  MXG_CHECK(pre == post, "mxg_mg_create: pre and post sweeps must be equal (symmetric cycle for CG)");
+  mxg_mg* mg = new mxg_mg();
+  mg->ctx = c; mg->nlevels = nlevels; mg->pre = pre; mg->post = post; mg->coarse = coarse;
+  mg->omega = omega; mg->cscale = cscale;
+  for (int l = 0; l < nlevels; ++l) {
+    MXG_CHECK(A[l] && !A[l]->is_complex && A[l]->nrows == A[l]->ncols_owned && A[l]->nghost == 0,
+              "mxg_mg_create: level %d must be a real square single-rank matrix", l);
+    mg->A.push_back(A[l]);
+    if (l + 1 < nlevels) {
+      MXG_CHECK(P && R && P[l] && R[l], "mxg_mg_create: missing transfer operator at level %d", l);
+      MXG_CHECK(P[l]->nrows == A[l]->nrows && P[l]->ncols_owned == A[l + 1]->nrows &&
+                R[l]->nrows == A[l + 1]->nrows && R[l]->ncols_owned == A[l]->nrows,
+                "mxg_mg_create: transfer operator shapes do not chain at level %d", l);
+      mg->P.push_back(P[l]); mg->R.push_back(R[l]);
+    }
+    mxg_mv *r, *z, *t;
+    MXG_TRY(mxg_mv_create(c, A[l]->nrows, 1, 0, &r));
+    MXG_TRY(mxg_mv_create(c, A[l]->nrows, 1, 0, &z));
+    MXG_TRY(mxg_mv_create(c, A[l]->nrows, 1, 0, &t));
+    mg->r.push_back(r); mg->z.push_back(z); mg->t.push_back(t);
+  }
+  *out = mg;
+  return 0;
+}
+
+extern "C" int mxg_mg_destroy(mxg_mg* mg) {
+  if (!mg) return 0;
+  for (auto* v : mg->r) mxg_mv_destroy(v);
+  for (auto* v : mg->z) mxg_mv_destroy(v);
+  for (auto* v : mg->t) mxg_mv_destroy(v);
+  delete mg;
+  return 0;
+}
+
+extern "C" int mxg_mg_apply(mxg_ctx* c, mxg_mg* mg, const mxg_mv* r, mxg_mv* z) {
+  MXG_CHECK(c && mg && r && z, "mxg_mg_apply: NULL argument");
+  MXG_CHECK(r->k == 1 && z->k == 1 && r->nlocal == mg->A[0]->nrows && z->nlocal == r->nlocal && !r->is_complex,
+            "mxg_mg_apply: shape mismatch");
+  MXG_TRY(mxg_mv_copy(mg->r[0], r));
+  MXG_TRY(mg_cycle(mg, 0));
+  return mxg_mv_copy(z, mg->z[0]);
+}
+
+namespace {
+
+bool cg_fused_ok(const mxg_csr* A, const mxg_solve_opts* o) {
+  return !A->is_complex && A->pipe_geo == 10 && A->npipe > 0 && (A->kernel & 0x30000) && o->precond <= 1;
+}
+
+// one right-hand side; x: initial guess in, solution out.  r, z, p, q: work vectors.
+int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, mxg_mv* x, mxg_mv* r,
+             mxg_mv* z, mxg_mv* p, mxg_mv* q, int max_iters, int* iters, double* res_out) {
+  constexpr int CHUNK = 16;
+  const long long n = A->nrows;
+  const int grid = mxg_grid_for(n, CGB, 4, 1024);
+  double* scal = c->d_result;
+  const double* diag = o->precond == 1 ? A->d_diag : nullptr;
+  auto allreduce = [&](double* ptr, int count) -> int {
+    if (c->comm) MXG_NCCL(ncclAllReduce(ptr, ptr, count, ncclDouble, ncclSum, c->comm, c->stream));
+    return 0;
+  };
+  double res = 0.0;
+  MXG_TRY(true_residual(c, A, b, x, r, &res));
+  int it = 0;
+  while (res > o->tol && it < max_iters) {
+    MXG_TRY(apply_prec(c, A, o, r, z));
+    MXG_TRY(mxg_mv_copy(p, z));
+    MXG_TRY(mxg_dev_dot(c, r->desc(), z->desc(), scal + S_RZ0));
+    MXG_TRY(allreduce(scal + S_RZ0, 1));
+    int cur = S_RZ0;
+    double rnorm = res;
+    bool stalled = false;
+    while (rnorm > o->tol && it < max_iters) {
+      const int todo = std::min(CHUNK, max_iters - it);
+      for (int s = 0; s < todo; ++s) {
+        const int nxt = cur == S_RZ0 ? S_RZ1 : S_RZ0;
+        MXG_TRY(mxg_dev_csr_apply_dot(c, A, p, q, scal + S_PQ));
+        MXG_TRY(allreduce(scal + S_PQ, 1));
+        hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(CGB), 0, c->stream, n, x->colptr(0), r->colptr(0),
+                           (const double*)p->colptr(0), (const double*)q->colptr(0), z->colptr(0), diag,
+                           (const double*)scal, cur, c->d_partial);
+        hipLaunchKernelGGL(k_cg_reduce2, dim3(2), dim3(CGB), 0, c->stream, (const double*)c->d_partial, grid,
+                           scal, nxt);
+        if (c->comm) {   // r.z and r.r sit in different slots: two tiny all-reduces
+          MXG_TRY(allreduce(scal + nxt, 1));
+          MXG_TRY(allreduce(scal + S_RR, 1));
+        }
+        hipLaunchKernelGGL(k_cg_dir, dim3(grid), dim3(CGB), 0, c->stream, n, p->colptr(0),
+                           (const double*)z->colptr(0), (const double*)scal, cur, nxt);
+        cur = nxt;
+      }
+      MXG_HIP(hipGetLastError());
+      it += todo;
+      MXG_HIP(hipMemcpyAsync(c->h_result, scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+      MXG_HIP(hipStreamSynchronize(c->stream));
+      const double rr = c->h_result[S_RR];
+      if (!(rr == rr) || c->h_result[S_PQ] == 0.0) { stalled = true; break; }   // NaN or breakdown
+      rnorm = sqrt(rr);
+    }
+    const double prev = res;
+    MXG_TRY(true_residual(c, A, b, x, r, &res));
+    if (stalled || rnorm > o->tol || !(res < prev)) break;   // cap reached / no progress: report
+  }
+  *iters = it;
+  *res_out = res;
+  return 0;
 }
 
 }  // namespace
@@ -95,8 +366,16 @@ extern "C" int mxg_solve_cg(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_m
     MXG_TRY(g.view(const_cast<mxg_mv*>(b), col, 1, &bj));
     MXG_TRY(g.view(x, col, 1, &xj));
     double res = 0.0;
-    MXG_TRY(true_residual(c, A, bj, xj, r, &res));
     int it = 0;
+    if (cg_fused_ok(A, o)) {
+      MXG_TRY(mxg_ctx_reserve_reduce(c, 8));
+      MXG_TRY(cg_fused(c, const_cast<mxg_csr*>(A), o, bj, xj, r, z, p, q, max_iters, &it, &res));
+      info->iters += it;
+      if (res > info->true_res) info->true_res = res;
+      if (res > o->tol) info->converged = 0;
+      continue;
+    }
+    MXG_TRY(true_residual(c, A, bj, xj, r, &res));
     // outer loop = the reference's `while (trueRes > linTol)` (src/MxMagWaveOp.cpp:876-885)
     while (res > o->tol && it < max_iters) {
       MXG_TRY(apply_prec(c, A, o, r, z));

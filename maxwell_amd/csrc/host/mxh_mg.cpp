@@ -1,0 +1,72 @@
+// C ABI over the multigrid setup (include/mxh.h, mxh_mg_*).
+#include <memory>
+#include <stdexcept>
+
+#include "mx_mg.hpp"
+#include "mxh.h"
+#include "mxh_internal.hpp"
+
+struct mxh_mg {
+  mxg_ctx* ctx = nullptr;
+  std::vector<mxg_csr*> A, P, R;
+  std::vector<int64_t> rows, nnz;
+  mxg_mg* mg = nullptr;
+  ~mxh_mg() {
+    if (mg) mxg_mg_destroy(mg);
+    for (auto* m : A) mxg_csr_destroy(m);
+    for (auto* m : P) mxg_csr_destroy(m);
+    for (auto* m : R) mxg_csr_destroy(m);
+  }
+};
+
+static mxg_csr* upload(mxg_ctx* ctx, const mx::Csr<double>& m) {
+  mxg_csr* d = nullptr;
+  if (mxg_csr_create(ctx, m.nrows, m.ncols, 0, m.rowptr.data(), m.col.data(), m.val.data(), 0, nullptr, &d) != 0)
+    throw std::runtime_error(std::string("mxg_csr_create: ") + mxg_last_error());
+  return d;
+}
+
+mxh_mg* mxh_mg_build(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::YeeField& F, const int n[3],
+                     int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
+                     double coarse_scale) {
+  mx::MgHierarchy h = mx::buildAggregationHierarchy(A0, F.gids, F.ncomp, n, min_coarse, max_levels);
+  std::unique_ptr<mxh_mg> g(new mxh_mg());
+  g->ctx = ctx;
+  for (auto& m : h.A) { g->A.push_back(upload(ctx, m)); g->rows.push_back(m.nrows); g->nnz.push_back(m.nnz()); }
+  for (auto& m : h.P) g->P.push_back(upload(ctx, m));
+  for (auto& m : h.R) g->R.push_back(upload(ctx, m));
+  if (mxg_mg_create(ctx, (int)g->A.size(), g->A.data(), g->P.data(), g->R.data(), sweeps, sweeps, coarse_sweeps,
+                    omega, coarse_scale, &g->mg) != 0)
+    throw std::runtime_error(std::string("mxg_mg_create: ") + mxg_last_error());
+  return g.release();
+}
+
+extern "C" int mxh_mg_create(mxg_ctx* ctx, mxh_sim* sim, const char* op, double shift, int64_t min_coarse,
+                             int max_levels, int sweeps, int coarse_sweeps, double omega, double coarse_scale,
+                             mxh_mg** out) {
+  try {
+    if (!ctx || !sim || !op || !out) throw std::runtime_error("mxh_mg_create: NULL argument");
+    if (sim->asmb->isWindowed()) throw std::runtime_error("mxh_mg_create: single-rank simulations only");
+    const std::string nm(op);
+    const mx::Csr<double>* A0;
+    const mx::YeeField* F;
+    if (nm == "shifted") { A0 = &mxh_sim_shifted_matrix(sim, shift); F = &sim->asmb->bfield(); }
+    else if (nm == "scaLapl") { A0 = &sim->ops.at("scaLapl"); F = &sim->asmb->psifield(); }
+    else throw std::runtime_error("mxh_mg_create: operator must be 'shifted' or 'scaLapl'");
+    *out = mxh_mg_build(ctx, *A0, *F, sim->cfg.n, min_coarse, max_levels, sweeps, coarse_sweeps, omega, coarse_scale);
+    return 0;
+  } catch (const std::exception& e) {
+    mxh_set_error(e.what());
+    return 1;
+  }
+}
+
+extern "C" int mxh_mg_destroy(mxh_mg* mg) { delete mg; return 0; }
+extern "C" mxg_mg* mxh_mg_handle(mxh_mg* mg) { return mg->mg; }
+extern "C" mxg_csr* mxh_mg_fine_matrix(mxh_mg* mg) { return mg->A[0]; }
+extern "C" int mxh_mg_level_sizes(mxh_mg* mg, int64_t* rows, int64_t* nnz, int* nlevels) {
+  const int n = (int)std::min<size_t>(mg->rows.size(), 16);
+  for (int i = 0; i < n; ++i) { if (rows) rows[i] = mg->rows[i]; if (nnz) nnz[i] = mg->nnz[i]; }
+  if (nlevels) *nlevels = n;
+  return 0;
+}

@@ -26,7 +26,7 @@ def _oracle_physical_modes(o, shift, want):
     return np.sort(out)[:want]
 
 
-@pytest.mark.parametrize("lin_type,prec", [("cg", "jacobi"), ("gmres", "none")])
+@pytest.mark.parametrize("lin_type,prec", [("cg", "jacobi"), ("gmres", "none"), ("cg", "amg")])
 def test_pillbox16_eigenvalues_match_oracle(ctx, oracle_pillbox16, lin_type, prec):
     _, o = oracle_pillbox16
     shift = yee.default_shift([1, 1, 1])
@@ -71,7 +71,7 @@ def test_pillbox32_analytic_modes(ctx):
     te111 = (1.8411837813406593 / 0.4) ** 2 + (np.pi / 0.8) ** 2
     sim = mx.Sim.pillbox(32)
     params = mx.SolverParams(nev=3, basis=30, tol=1e-8, shift=yee.default_shift([1, 1, 1]), lin_type="cg",
-                             lin_tol=1e-9, prec_type="jacobi")
+                             lin_tol=1e-9, prec_type="amg")
     solver = mx.Solver(ctx, sim, params)
     assert solver.solve() == 3
     k2 = np.sort([solver.result(i)["k2"].real for i in range(3)])

@@ -77,3 +77,36 @@ def test_unconverged_is_reported_not_spun(ctx, oracle_pillbox12, rng):
     x = mx.MultiVec(ctx, A.shape[0], 1)
     iters, conv, res = dev.solve(b, x, method="cg", tol=1e-14, max_iters=5)
     assert not conv and iters <= 6 and res > 1e-14
+
+
+def test_multigrid_preconditioner(ctx, rng):
+    """K11 replacement: the aggregation V-cycle is a fixed symmetric operator (legal for CG), cuts the
+    iteration count by an order of magnitude, and the solution is the same."""
+    sim = mx.Sim.pillbox(32)
+    shift = yee.default_shift([1, 1, 1])
+    for op in ("shifted", "scaLapl"):
+        mg = mx.Multigrid(ctx, sim, op, shift, min_coarse=500)
+        assert len(mg.levels) >= 3 and mg.levels[-1][0] < mg.levels[0][0] // 30
+        A = mg.fine_matrix()
+        n = A.nrows
+        host = sim.op("vecLapl", shift=shift) if op == "shifted" else sim.op("scaLapl")
+        # symmetry of the cycle: <u, M v> == <M u, v>
+        u, v = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        U, V = mx.MultiVec.from_numpy(ctx, u), mx.MultiVec.from_numpy(ctx, v)
+        MU, MV = mx.MultiVec(ctx, n, 1), mx.MultiVec(ctx, n, 1)
+        mg.apply(U, MU); mg.apply(V, MV)
+        a, b = float(np.dot(u, MV.to_numpy()[:, 0])), float(np.dot(MU.to_numpy()[:, 0], v))
+        assert abs(a - b) <= 1e-10 * max(abs(a), abs(b))
+        assert a != 0.0
+        if op == "shifted":
+            rhs = sim.op("mRhs") @ rng.uniform(-1, 1, n)
+        else:
+            rhs = sim.op("divB") @ (sim.op("mRhs") @ rng.uniform(-1, 1, sim.op("mRhs").shape[0]))
+        bvec = mx.MultiVec.from_numpy(ctx, rhs)
+        xj, xm = mx.MultiVec(ctx, n, 1), mx.MultiVec(ctx, n, 1)
+        itj, cj, _ = A.solve(bvec, xj, method="cg", tol=1e-9, precond="jacobi")
+        itm, cm, resm = A.solve(bvec, xm, method="cg", tol=1e-9, precond="mg", mg=mg)
+        assert cj and cm and itm * 5 < itj and itm < 60
+        assert np.linalg.norm(host @ xm.to_numpy()[:, 0] - rhs) <= 2e-9
+        if op == "shifted":   # non-singular: both solves agree
+            assert np.linalg.norm(xm.to_numpy() - xj.to_numpy()) <= 1e-7 * np.linalg.norm(xj.to_numpy())
