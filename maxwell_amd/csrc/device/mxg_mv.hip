@@ -196,8 +196,9 @@ __global__ void k_trans_mv(MvDesc A, MvDesc T, int l0, int j0, int m, double* __
       if (CPLX) acc[l][j][1] = 0.0;
     }
   const long long stride = (long long)gridDim.x * BLK;
+  if constexpr (CPLX) {
   for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
-    if (CPLX) {
+    {
       double2 tv[KT];
 #pragma unroll
       for (int j = 0; j < KT; ++j) tv[j] = reinterpret_cast<const double2*>(tp[j])[i];
@@ -210,16 +211,28 @@ __global__ void k_trans_mv(MvDesc A, MvDesc T, int l0, int j0, int m, double* __
           acc[l][j][1] += av.x * tv[j].y - av.y * tv[j].x;
         }
       }
-    } else {
-      double tv[KT];
+    }
+  }
+  }
+  if constexpr (!CPLX) {
+    // real: two rows per thread and iteration through 16-byte loads
+    const long long npair = n / 2;
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < npair; i += stride) {
+      double2 tv[KT];
 #pragma unroll
-      for (int j = 0; j < KT; ++j) tv[j] = tp[j][i];
+      for (int j = 0; j < KT; ++j) tv[j] = reinterpret_cast<const double2*>(tp[j])[i];
 #pragma unroll
       for (int l = 0; l < LT; ++l) {
-        double av = ap[l][i];
+        const double2 av = reinterpret_cast<const double2*>(ap[l])[i];
 #pragma unroll
-        for (int j = 0; j < KT; ++j) acc[l][j][0] += av * tv[j];
+        for (int j = 0; j < KT; ++j) acc[l][j][0] += av.x * tv[j].x + av.y * tv[j].y;
       }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+      for (int l = 0; l < LT; ++l)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[l][j][0] += ap[l][n - 1] * tp[j][n - 1];
     }
   }
   const int width = CPLX ? 2 : 1;
@@ -242,58 +255,54 @@ __global__ void k_trans_mv(MvDesc A, MvDesc T, int l0, int j0, int m, double* __
 template <int KT, bool CPLX>
 __global__ void k_times_mat(MvDesc A, const double* __restrict__ Bs, int m, int j0, int kcols,
                             double br, double bi, MvDesc Y) {
+  // one element = one complex number, or two consecutive real rows (16-byte accesses either way)
   const long long n = Y.n;
-  const int width = CPLX ? 2 : 1;
+  const long long nelem = CPLX ? n : n / 2;
   const long long stride = (long long)gridDim.x * BLK;
-  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
-    double acc[KT][CPLX ? 2 : 1];
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < nelem; i += stride) {
+    double2 acc[KT];
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      acc[j][0] = 0.0;
-      if (CPLX) acc[j][1] = 0.0;
-    }
+    for (int j = 0; j < KT; ++j) acc[j] = make_double2(0.0, 0.0);
     for (int l = 0; l < m; ++l) {
-      const double* a = A.col(l);
-      if (CPLX) {
-        double2 av = reinterpret_cast<const double2*>(a)[i];
+      const double2 av = reinterpret_cast<const double2*>(A.col(l))[i];
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
-          const int jj = min(j0 + j, kcols - 1);
+      for (int j = 0; j < KT; ++j) {
+        const int jj = min(j0 + j, kcols - 1);
+        if (CPLX) {
           const double bre = Bs[((size_t)l + (size_t)m * jj) * 2];
           const double bim = Bs[((size_t)l + (size_t)m * jj) * 2 + 1];
-          acc[j][0] += av.x * bre - av.y * bim;
-          acc[j][1] += av.x * bim + av.y * bre;
-        }
-      } else {
-        double av = a[i];
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-          const int jj = min(j0 + j, kcols - 1);
-          acc[j][0] += av * Bs[(size_t)l + (size_t)m * jj];
+          acc[j].x += av.x * bre - av.y * bim;
+          acc[j].y += av.x * bim + av.y * bre;
+        } else {
+          const double b = Bs[(size_t)l + (size_t)m * jj];
+          acc[j].x += av.x * b;
+          acc[j].y += av.y * b;
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
       if (j0 + j >= kcols) break;
-      double* y = Y.col(j0 + j);
-      if (CPLX) {
-        double2* y2 = reinterpret_cast<double2*>(y);
-        double2 r = make_double2(acc[j][0], acc[j][1]);
-        if (br != 0.0 || bi != 0.0) {
-          double2 v = y2[i];
-          r.x += br * v.x - bi * v.y;
-          r.y += br * v.y + bi * v.x;
-        }
-        y2[i] = r;
-      } else {
-        double r = acc[j][0];
-        if (br != 0.0) r += br * y[i];
-        y[i] = r;
+      double2* y2 = reinterpret_cast<double2*>(Y.col(j0 + j));
+      double2 r = acc[j];
+      if (br != 0.0 || (CPLX && bi != 0.0)) {
+        const double2 v = y2[i];
+        if (CPLX) { r.x += br * v.x - bi * v.y; r.y += br * v.y + bi * v.x; }
+        else { r.x += br * v.x; r.y += br * v.y; }
       }
+      y2[i] = r;
     }
   }
-  (void)width;
+  if (!CPLX && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd tail of real columns
+    const long long i = n - 1;
+    for (int j = 0; j < KT; ++j) {
+      if (j0 + j >= kcols) break;
+      double acc1 = 0.0;
+      for (int l = 0; l < m; ++l) acc1 += A.col(l)[i] * Bs[(size_t)l + (size_t)m * (j0 + j)];
+      double* y = Y.col(j0 + j);
+      y[i] = br != 0.0 ? acc1 + br * y[i] : acc1;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- random (K9)
@@ -606,7 +615,7 @@ extern "C" int mxg_mv_times_mat(double alr, double ali, const mxg_mv* A, const d
   MXG_TRY(mxg_ctx_reserve_small(c, Bs.size()));
   MXG_HIP(hipMemcpyAsync(c->d_small, Bs.data(), sizeof(double) * Bs.size(), hipMemcpyHostToDevice,
                          c->stream));
-  const int grid = mxg_grid_for(self->nlocal, BLK, 1, 8 * c->num_cu);
+  const int grid = mxg_grid_for(self->is_complex ? self->nlocal : (self->nlocal + 1) / 2, BLK, 1, 8 * c->num_cu);
   if (self->nlocal > 0) {
     if (cplx) dispatch_times_mat<true>(c, grid, A->desc(), c->d_small, m, k, ber, bei, self->desc());
     else dispatch_times_mat<false>(c, grid, A->desc(), c->d_small, m, k, ber, bei, self->desc());
@@ -637,7 +646,7 @@ extern "C" int mxg_mv_trans_mv(double alr, double ali, const mxg_mv* A, const mx
   const int w = cplx ? 2 : 1;
   const size_t width = (size_t)m * k * w;
   MXG_TRY(mxg_ctx_reserve_reduce(c, width));
-  const int gx = mxg_grid_for(self->nlocal, BLK, 4, 1024);
+  const int gx = mxg_grid_for(self->is_complex ? self->nlocal : (self->nlocal + 1) / 2, BLK, 4, 1024);
   MvDesc Ad = A->desc(), Td = self->desc();
   if (cplx) {
     if (k >= 4) launch_trans_mv<4, 4, true>(c, gx, Ad, Td, m, k);
