@@ -63,3 +63,16 @@ def test_error_paths(built):
         mx.Sim(4, pec_shape="blob(1;2)")
     with pytest.raises(mx.MxError, match="boundary"):
         mx.Sim(4, lower=("open", "pec", "pec"))
+
+
+def test_config3_curved_pec_cylinder_matches_oracle(built):
+    """BASELINE config 3 geometry at test size: z-axis PEC cylinder without caps, periodic in z
+    (Dey-Mittra cut cells all along the wall: irregular nnz/row)."""
+    from oracle import geometry as geo
+    kw = dict(origin=(-0.5, -0.5, -0.5), size=(1.0, 1.0, 1.0))
+    o = yee.YeeSim(10, pec=geo.Cylinder(0.4, [0, 0, 1], [0, 0, 0]), **kw).wave_ops()
+    sim = mx.Sim(10, pec_shape="cylinder(0.4;0,0,1;0,0,0)", **kw)
+    for name, ref in o.items():
+        assert _same(sim.op(name), ref), name
+    rows = np.diff(o["vecLapl"].indptr)
+    assert rows.max() > 7 and (rows == 7).sum() > 0      # wall rows wider than the bulk stencil

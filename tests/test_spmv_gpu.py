@@ -236,3 +236,21 @@ def test_halo_exchange_on_a_one_rank_communicator(built, oracle_pillbox12, rng):
             obj.close()
     finally:
         ctx1.close()
+
+
+def test_config3_cylinder_and_config5_sphere_geometries(ctx, rng):
+    """Parity cases of BASELINE configs 3 and 5 (geometry only: curved PEC cylinder periodic in z;
+    PEC sphere octant with PEC/PMC walls) at test size: bit-exact SpMV and SpMM (8 right-hand sides)."""
+    cases = [dict(n=14, origin=(-0.5,) * 3, size=(1.0,) * 3, pec_shape="cylinder(0.4;0,0,1;0,0,0)"),
+             dict(n=[12, 13, 14], origin=(0.0,) * 3, size=(0.5,) * 3, pec_shape="sphere(0.49;0,0,0)",
+                  lower=("pmc", "pec", "pmc"), upper=("pec", "pec", "pec"))]
+    for kw in cases:
+        n = kw.pop("n")
+        sim = mx.Sim(n, **kw)
+        for name in ("vecLapl", "curlCurl"):
+            host = sim.op(name)
+            A = sim.to_device(ctx, name)
+            x = rng.uniform(-1, 1, (host.shape[1], 8))
+            X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, host.shape[0], 8)
+            A.apply(X, Y)
+            assert np.array_equal(Y.to_numpy(), cref.spmv(host, x))
