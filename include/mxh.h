@@ -10,6 +10,7 @@
 #ifndef MXH_H
 #define MXH_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "mxg.h"
@@ -121,6 +122,30 @@ int mxh_solver_stats(mxh_solver* s, int* num_applies, int* vec_lin_iters, int* s
                      double* vec_solve_seconds, double* sca_solve_seconds, double* eigensolve_seconds);
 /* copy eigenvector i of the B field (local rows) to host */
 int mxh_solver_eigvec(mxh_solver* s, int i, double* out);
+
+/* ---------------------------------------------------------------------------------------
+ * `.mx` input deck front end: MxProblem (src/MxProblem.cpp:201-706) behind the `maxwell` binary
+ * (src/maxwell.cpp:41-120, `maxwell --infile=pillbox.mx`).  Parsing needs no GPU.
+ * ------------------------------------------------------------------------------------- */
+typedef struct mxh_problem mxh_problem;
+/* parse deck text / a deck file; `strict` as in mxh_sim_create */
+int mxh_problem_parse(const char* mx_text, int strict, mxh_problem** out);
+int mxh_problem_load(const char* path, int strict, mxh_problem** out);
+int mxh_problem_destroy(mxh_problem* p);
+/* value of a parameter-list entry as text ("eigensolver : nev", "linear solver : prec type",
+ * "linear solver : ilu : drop tol", "polarization", ...; the keys of src/MxProblem.cpp:82-105).
+ * Returns 1 if the key is not set. */
+int mxh_problem_param(mxh_problem* p, const char* key, char* buf, size_t buflen);
+/* <Grid>, <BoundaryConditions> (0 periodic, 1 pec, 2 pmc per side) and the <PEC> D-M frac */
+int mxh_problem_grid(mxh_problem* p, int n[3], double origin[3], double size[3], int lower[3],
+                     int upper[3], double* dm_frac, int* has_pec);
+/* level-set value of the <PEC> shape at a point (MxShape::func, > 0 inside) */
+int mxh_problem_pec_func(mxh_problem* p, const double xyz[3], double* f);
+/* assemble (once) and return the simulation; owned by the problem */
+int mxh_problem_sim(mxh_problem* p, mxh_sim** sim);
+/* MxSolver with the deck's parameters on `ctx`; owned by the caller (mxh_solver_destroy) and
+ * valid while the problem lives.  `verbose` < 0 keeps the deck's "output" level. */
+int mxh_problem_solver(mxg_ctx* ctx, mxh_problem* p, int verbose, mxh_solver** out);
 
 #ifdef __cplusplus
 }

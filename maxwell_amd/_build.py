@@ -2,6 +2,7 @@
 
   libmxg.so     HIP kernels + the C ABI of include/mxg.h       (hipcc --offload-arch=gfx950)
   libmxhost.so  host C++: assembly, drop-in classes, eigen-driver, C ABI of include/mxh.h (g++)
+  maxwell       the reference's command line: `maxwell --infile=deck.mx`                (g++)
 
 hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the CPU-only
 container; the built .so files travel to the GPU box with the repository snapshot.
@@ -18,7 +19,9 @@ INCLUDE = os.path.join(ROOT, "include")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 DEVICE_SOURCES = ["mxg_ctx.hip", "mxg_mv.hip", "mxg_csr.hip", "mxg_solve.hip"]
-HOST_SOURCES = ["mx_geometry.cpp", "mx_yee.cpp", "mxh_sim.cpp", "mxh_mg.cpp", "mxh_solver.cpp"]
+HOST_SOURCES = ["mx_geometry.cpp", "mx_yee.cpp", "mxh_sim.cpp", "mxh_mg.cpp", "mxh_solver.cpp",
+                "mxh_problem.cpp"]
+CLI_SOURCE = "maxwell.cpp"          # the reference's `maxwell --infile=deck.mx` entry point
 
 
 def _digest(sources, extra=""):
@@ -88,6 +91,12 @@ def build_host(force=False):
     cmd = ["g++", "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-I" + INCLUDE, "-I" + os.path.join(INCLUDE, "mx"), "-I" + src_dir] + HOST_SOURCES + \
           ["-o", target, "-L" + LIBDIR, "-lmxg", "-Wl,-rpath,$ORIGIN"]
+    _run(cmd, src_dir)
+    # the command-line front end, next to the libraries it links
+    cli = os.path.join(LIBDIR, "maxwell")
+    cmd = ["g++", "-O2", "-fopenmp", "-std=c++17", "-ffp-contract=off",
+           "-I" + INCLUDE, "-I" + os.path.join(INCLUDE, "mx"), "-I" + src_dir, CLI_SOURCE,
+           "-o", cli, "-L" + LIBDIR, "-lmxhost", "-lmxg", "-Wl,-rpath,$ORIGIN"]
     _run(cmd, src_dir)
     _write_stamp(target, deps, dev_stamp)
     return target

@@ -121,6 +121,15 @@ MXH_SIGNATURES = {
     "mxh_solver_result": (C.c_int, [vp, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "mxh_solver_stats": (C.c_int, [vp, c_ip, c_ip, c_ip, c_dp, c_dp, c_dp]),
     "mxh_solver_eigvec": (C.c_int, [vp, C.c_int, vp]),
+    "mxh_problem_parse": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
+    "mxh_problem_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
+    "mxh_problem_destroy": (C.c_int, [vp]),
+    "mxh_problem_param": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "mxh_problem_grid": (C.c_int, [vp, C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int), c_dp, c_ip]),
+    "mxh_problem_pec_func": (C.c_int, [vp, c_dp, c_dp]),
+    "mxh_problem_sim": (C.c_int, [vp, C.POINTER(vp)]),
+    "mxh_problem_solver": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
 }
 
 _cache = {}

@@ -411,9 +411,12 @@ class SolverParams:
 class Solver:
     """MxSolver: block Krylov-Schur in shift-invert mode around MxMagWaveOp::Apply."""
 
-    def __init__(self, ctx, sim, params=None):
+    def __init__(self, ctx, sim, params=None, _handle=None):
         self.lib = _lib.load_mxhost()
         self.ctx, self.sim = ctx, sim
+        if _handle is not None:          # created by Problem.solver() from a deck
+            self.params, self.h = None, _handle
+            return
         self.params = params or SolverParams()
         h = C.c_void_p()
         _chk(self.lib.mxh_solver_create(ctx.h, sim.h, C.byref(self.params.c), C.byref(h)), self.lib, "mxh")
@@ -448,6 +451,77 @@ class Solver:
     def close(self):
         if self.h:
             self.lib.mxh_solver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Problem:
+    """A `.mx` input deck (MxProblem, src/MxProblem.cpp:201-706): parsed on the host, assembled on
+    demand (`sim()`), solved on the GPU with the deck's own parameters (`solver(ctx)`)."""
+
+    BC_NAMES = ("periodic", "pec", "pmc")
+
+    def __init__(self, text=None, path=None, strict=True):
+        self.lib = _lib.load_mxhost()
+        h = C.c_void_p()
+        if (text is None) == (path is None):
+            raise ValueError("Problem: give exactly one of text= or path=")
+        if text is not None:
+            _chk(self.lib.mxh_problem_parse(text.encode(), int(bool(strict)), C.byref(h)), self.lib, "mxh")
+        else:
+            _chk(self.lib.mxh_problem_load(str(path).encode(), int(bool(strict)), C.byref(h)), self.lib, "mxh")
+        self.h = h
+        self._sim = None
+
+    def param(self, key, default=None):
+        buf = C.create_string_buffer(256)
+        if self.lib.mxh_problem_param(self.h, key.encode(), buf, len(buf)) != 0:
+            if default is None:
+                raise KeyError(key)
+            return default
+        return buf.value.decode()
+
+    def grid(self):
+        n, lo, up = (C.c_int * 3)(), (C.c_int * 3)(), (C.c_int * 3)()
+        o, s = (C.c_double * 3)(), (C.c_double * 3)()
+        dm, has = C.c_double(), C.c_int()
+        _chk(self.lib.mxh_problem_grid(self.h, n, o, s, lo, up, C.byref(dm), C.byref(has)), self.lib, "mxh")
+        return dict(n=list(n), origin=list(o), size=list(s), lower=[self.BC_NAMES[i] for i in lo],
+                    upper=[self.BC_NAMES[i] for i in up], dm_frac=dm.value, has_pec=bool(has.value))
+
+    def pec_func(self, xyz):
+        p = (C.c_double * 3)(*xyz)
+        f = C.c_double()
+        _chk(self.lib.mxh_problem_pec_func(self.h, p, C.byref(f)), self.lib, "mxh")
+        return f.value
+
+    def sim(self):
+        """The assembled simulation (owned by the problem; a Sim view that does not free it)."""
+        if self._sim is None:
+            h = C.c_void_p()
+            _chk(self.lib.mxh_problem_sim(self.h, C.byref(h)), self.lib, "mxh")
+            view = Sim.__new__(Sim)
+            view.lib, view.h, view.n = self.lib, h, self.grid()["n"]
+            view.close = lambda: None
+            view._owner = self
+            self._sim = view
+        return self._sim
+
+    def solver(self, ctx, verbose=0):
+        h = C.c_void_p()
+        _chk(self.lib.mxh_problem_solver(ctx.h, self.h, int(verbose), C.byref(h)), self.lib, "mxh")
+        s = Solver(ctx, self.sim(), _handle=h)
+        s._owner = self
+        return s
+
+    def close(self):
+        if self.h:
+            self.lib.mxh_problem_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -265,7 +265,10 @@ std::complex<double> YeeAssembler<S>::baseFactor(const YeeField& F, int comp, co
 template <typename S>
 std::complex<double> YeeAssembler<S>::factor(const YeeField& F, int comp, const int c[3]) const {
   const std::complex<double> res = baseFactor(F, comp, c);
-  if (&F == &B_) return res;                                   // src/MxYeeFitBField.cpp:83-90 (dmFrac 0)
+  if (&F == &B_) {                                             // src/MxYeeFitBField.cpp:83-90
+    if (cfg_.dmFrac > 0.0 && !F.frac.empty() && fracAt(F, comp, c) < cfg_.dmFrac) return 0.0;
+    return res;
+  }
   int probe[3] = {c[0], c[1], c[2]};
   if (!cfg_.strict) interior(F, comp, c, probe);
   return use(F, comp, probe) ? res : std::complex<double>(0.0);  // src/MxYeeFitEField.cpp:91-98, MxYeePsiField.cpp:117-124

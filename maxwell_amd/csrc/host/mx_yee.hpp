@@ -45,6 +45,7 @@ struct YeeConfig {
   // MxYeeFitEField/MxYeePsiField::getCompFactor (drops periodic wrap entries of curlE at the
   // upper boundary); false: test the interiorised cell
   bool strict = true;
+  double dmFrac = 0.0;   // <PEC> 'D-M frac' (src/MxProblem.cpp:450): B faces below it get factor 0
   // Distributed assembly (one GPU per MxGridDomain box, src/MxGrid.cpp:171-193): the cells this
   // rank owns, [boxLo, boxHi) per axis; boxHi[i] < 0 means the whole axis, [0, n+1).  The
   // assembler works on the box grown by `halo` cells wherever the axis is split, so the owned rows

@@ -4,20 +4,20 @@
 #include "mx/MxSolver.h"
 #include "mxh.h"
 #include "mxh_internal.hpp"
-
-struct mxh_solver {
-  RCP<MxComm> comm;
-  RCP<MxEMSim<3> > sim;
-  std::unique_ptr<MxSolver<3, double> > solver;
-  mxh_solver_params params;
-  std::string linType, precType;
-};
+#include "mxh_solver_internal.hpp"
 
 extern "C" void mxh_solver_default_params(mxh_solver_params* p) {
   // defaults of src/MxProblem.cpp:26-46
   p->nev = 10; p->basis = 20; p->block_size = 1; p->max_restarts = 100; p->tol = 1.0e-6; p->shift = 0.0;
   p->lin_type = "gmres"; p->lin_basis = 40; p->lin_tol = 1.0e-6; p->prec_type = "none";
   p->verbose = 0; p->seed = 12345;
+}
+
+void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::ParameterList const& pl) {
+  s.comm = rcp(new MxComm(ctx));
+  s.params.shift = pl.get("eigensolver : shift", 0.0);
+  s.sim = rcp(new MxEMSim<3>(sim->cfg, s.comm, pl, sim->asmb));
+  s.solver.reset(new MxSolver<3, double>(s.sim, pl));
 }
 
 extern "C" int mxh_solver_create(mxg_ctx* ctx, mxh_sim* sim, const mxh_solver_params* p, mxh_solver** out) {
@@ -27,7 +27,6 @@ extern "C" int mxh_solver_create(mxg_ctx* ctx, mxh_sim* sim, const mxh_solver_pa
     s->params = *p;
     s->linType = p->lin_type ? p->lin_type : "gmres";
     s->precType = p->prec_type ? p->prec_type : "none";
-    s->comm = rcp(new MxComm(ctx));
     Teuchos::ParameterList pl;
     pl.set("eigensolver : type", "krylov-schur");
     pl.set("eigensolver : nev", p->nev);
@@ -43,8 +42,7 @@ extern "C" int mxh_solver_create(mxg_ctx* ctx, mxh_sim* sim, const mxh_solver_pa
     pl.set("linear solver : basis", p->lin_basis);
     pl.set("linear solver : tol", p->lin_tol);
     pl.set("linear solver : prec type", s->precType.c_str());
-    s->sim = rcp(new MxEMSim<3>(sim->cfg, s->comm, pl, sim->asmb));
-    s->solver.reset(new MxSolver<3, double>(s->sim, pl));
+    mxh_solver_build(*s, ctx, sim, pl);
     *out = s.release();
     return 0;
   } catch (const std::exception& e) {

@@ -1,0 +1,23 @@
+// mxh_solver: shared by mxh_solver.cpp (parameter struct entry) and mxh_problem.cpp (.mx deck entry).
+#ifndef MXH_SOLVER_INTERNAL_HPP
+#define MXH_SOLVER_INTERNAL_HPP
+
+#include <memory>
+#include <string>
+
+#include "mx/MxSolver.h"
+#include "mxh.h"
+#include "mxh_internal.hpp"
+
+struct mxh_solver {
+  RCP<MxComm> comm;
+  RCP<MxEMSim<3> > sim;
+  std::unique_ptr<MxSolver<3, double> > solver;
+  mxh_solver_params params;
+  std::string linType, precType;
+};
+
+// comm + MxEMSim (sharing the assembler of `sim`) + MxSolver from a complete parameter list
+void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::ParameterList const& pl);
+
+#endif

@@ -37,7 +37,7 @@ class Shape:
         self._sync()
 
     def _sync(self):
-        self.Ainvb = self.Ainv @ self.b
+        self.Ainvb = np.array(self._sync_exact())
         self._a = self.Ainv.tolist()
         self._ab = self.Ainvb.tolist()
 
@@ -50,6 +50,50 @@ class Shape:
     def invert(self):
         self.sign *= -1.0
         return self
+
+    # generic transforms (src/MxShape.cpp:98-216): A <- T A, b <- T (b - p) + p, Ainv = A^-1.
+    # Plain Python floats in a fixed summation order, so the C++ host code can match bit for bit.
+    def _apply(self, T, p):
+        A = getattr(self, "A", None)
+        if A is None:
+            A = [[1.0 if i == j else 0.0 for j in range(3)] for i in range(3)]
+        self.A = _matmul3(T, A)
+        b = [float(x) for x in self.b]
+        d = [b[i] - p[i] for i in range(3)]
+        self.b = np.array([_row3(T[i], d) + p[i] for i in range(3)])
+        self.Ainv = np.array(_inverse3(self.A))
+        self._sync()
+        return self
+
+    def _sync_exact(self):
+        a = self.Ainv.tolist()
+        b = [float(x) for x in self.b]
+        return [_row3(a[i], b) for i in range(3)]
+
+    def rotate(self, axis, angle, pivot=None):
+        """src/MxShape.cpp:98-127 (Rodrigues); without a pivot: about the current translation."""
+        import math
+        nn = math.sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2])
+        a = [axis[0] / nn, axis[1] / nn, axis[2] / nn]
+        M = [[-0.0, a[2], -a[1]], [-a[2], -0.0, a[0]], [a[1], -a[0], -0.0]]
+        MM = _matmul3(M, M)
+        s, c1 = math.sin(angle), 1.0 - math.cos(angle)
+        R = [[(1.0 if i == j else 0.0) + (M[i][j] * s + MM[i][j] * c1) for j in range(3)] for i in range(3)]
+        p = [float(x) for x in (self.b if pivot is None else pivot)]
+        return self._apply(R, p)
+
+    def scale(self, magnitudes, origin=(0.0, 0.0, 0.0)):
+        """src/MxShape.cpp:163-172."""
+        S = [[float(magnitudes[i]) if i == j else 0.0 for j in range(3)] for i in range(3)]
+        return self._apply(S, [float(x) for x in origin])
+
+    def reflect(self, normal, point):
+        """src/MxShape.cpp:200-216."""
+        import math
+        nn = math.sqrt(normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2])
+        n = [normal[0] / nn, normal[1] / nn, normal[2] / nn]
+        M = [[(1.0 if i == j else 0.0) - 2.0 * n[i] * n[j] for j in range(3)] for i in range(3)]
+        return self._apply(M, [float(x) for x in point])
 
     # vectorised
     def _local(self, p):
@@ -213,6 +257,37 @@ def pillbox(radius=0.4, length=0.8):
 # ----------------------------------------------------------------------------
 # scalar helpers (Python float triples)
 # ----------------------------------------------------------------------------
+def _row3(r, v):
+    return r[0] * v[0] + r[1] * v[1] + r[2] * v[2]
+
+
+def _matmul3(x, y):
+    out = [[0.0] * 3 for _ in range(3)]
+    for i in range(3):
+        for j in range(3):
+            acc = 0.0
+            for k in range(3):
+                acc += x[i][k] * y[k][j]
+            out[i][j] = acc
+    return out
+
+
+def _inverse3(a):
+    """Cofactor inverse, same expression order as the host code (mx_geometry.cpp)."""
+    det = (a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) -
+           a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+           a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]))
+    return [[(a[1][1] * a[2][2] - a[1][2] * a[2][1]) / det,
+             (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det,
+             (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det],
+            [(a[1][2] * a[2][0] - a[1][0] * a[2][2]) / det,
+             (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det,
+             (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det],
+            [(a[1][0] * a[2][1] - a[1][1] * a[2][0]) / det,
+             (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det,
+             (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det]]
+
+
 def sgn(v):
     """src/MxUtil.hpp:44-49 with dEps = 0 (vectorised)."""
     return np.sign(v).astype(int)

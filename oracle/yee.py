@@ -61,13 +61,14 @@ class YeeSim:
 
     def __init__(self, N, origin=(0., 0., 0.), size=(1., 1., 1.),
                  lower=("periodic",) * 3, upper=("periodic",) * 3,
-                 pec=None, phase_shifts=(0., 0., 0.), strict=True):
+                 pec=None, phase_shifts=(0., 0., 0.), strict=True, dm_frac=0.0):
         self.n = np.array([int(N)] * 3 if np.isscalar(N) else [int(x) for x in N])
         self.origin = np.array(origin, dtype=float)
         self.size = np.array(size, dtype=float)
         self.d = self.size / self.n.astype(float)          # src/MxGrid.cpp:18
         self.pec = pec
         self.strict = strict
+        self.dm_frac = float(dm_frac)   # <PEC> 'D-M frac', src/MxProblem.cpp:450
         self.phase = np.exp(1j * np.array(phase_shifts, dtype=float))   # src/MxGridField.cpp:34-38
         self.is_complex = bool(np.any(np.array(phase_shifts) != 0.0))
         lower = [_bc(x) for x in lower]
@@ -198,7 +199,8 @@ class YeeSim:
 
     def b_use(self, cells):
         """MxYeeFitBField::useCompInMap, src/MxYeeFitBField.cpp:63-80: any used
-        component keeps the whole cell (the dmFrac test is unreachable with dmFrac 0)."""
+        component keeps the whole cell (the dmFrac test after the loop is unreachable: when the
+        loop falls through, the base rule is already false for `comp`)."""
         u = self.base_use(self.B, 0, cells)
         for c in (1, 2):
             u = u | self.base_use(self.B, c, cells)
@@ -263,6 +265,9 @@ class YeeSim:
     def factor(self, F, comp, cells):
         res = self.base_factor(F, comp, cells)
         if F is self.B:
+            # MxYeeFitBField::getCompFactor, src/MxYeeFitBField.cpp:83-90
+            if F.frac is not None and self.dm_frac > 0.0:
+                res = np.where(self.frac_at(F, comp, cells) < self.dm_frac, 0.0, res)
             return res
         probe = cells if self.strict else self.interior(F, comp, cells)
         return np.where(self.use(F, comp, probe), res, 0.0)
@@ -451,3 +456,26 @@ def default_shift(size):
 def pillbox_sim(N, **kw):
     """Config 1/2/4 input: example/pillbox.py with resolution N (unit box at -0.5)."""
     return YeeSim(N, origin=(-0.5,) * 3, size=(1.0,) * 3, pec=geo.pillbox(0.4, 0.8), **kw)
+
+
+def mag_wave_modes(ops, shift, want, used=None):
+    """Dense restatement of what MxSolver iterates on: T = P (L - sigma M)^-1 M with the
+    divergence-cleaning projection P = I + G S^+ D M (MxMagWaveOp::Apply, src/MxMagWaveOp.cpp:826-943:
+    solve with shiftedVecLapl, then scaLapl psi = divB mRhs b, b += gradPsi psi), restricted to the
+    B rows MxSolver leaves in its start vector (`used`; zeroUnusedComponents, src/MxSolver.cpp:65).
+    Returns k^2 = 1/theta + sigma for the `want` largest |theta| (eigValsToFreqs, :1253-1270).
+    Small problems only (dense algebra)."""
+    L = ops["vecLapl"].toarray(); M = ops["mRhs"].toarray()
+    D = ops["divB"].toarray(); G = ops["gradPsi"].toarray(); S = ops["scaLapl"].toarray()
+    n = L.shape[0]
+    if used is None:
+        used = (M.diagonal() > 0) & (np.abs(ops["curlE"]).sum(axis=1).A1 > 0)
+    idx = np.nonzero(used)[0]
+    A = (L - shift * M)[np.ix_(idx, idx)]
+    T = np.zeros((n, n))
+    T[np.ix_(idx, idx)] = np.linalg.solve(A, M[np.ix_(idx, idx)])
+    P = np.eye(n) + G @ np.linalg.pinv(S, rcond=1e-12) @ D @ M
+    T = (P @ T)[np.ix_(idx, idx)]
+    theta = np.linalg.eigvals(T)
+    theta = theta[np.argsort(-np.abs(theta))][:want]
+    return np.sort((1.0 / theta + shift).real)

@@ -1,0 +1,115 @@
+"""The reference's command line on the GPU: `maxwell --infile=deck.mx` (src/maxwell.cpp:41-120) and the
+same decks through mxh_problem_solver, against scipy's shift-invert of the oracle-assembled pencil.
+
+Decks are hand-written (tests/golden/*.mx headers).  The deck's own tolerances apply
+(eigensolver tol 1e-6 by default), so the comparison tolerance here is looser than the 1e-8 of
+tests/test_eigen_gpu.py, which drives the same solver with tight tolerances."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import maxwell_amd as mx
+from oracle import mxdeck, yee
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "maxwell_amd", "lib", "maxwell")
+C0 = 299792458.0
+
+
+def _oracle_modes(deck, want, strict=True):
+    """k^2 of the operator MxSolver iterates on, from the oracle's dense restatement of
+    MxMagWaveOp::Apply on the oracle-assembled matrices (oracle/yee.py mag_wave_modes)."""
+    o = deck.sim(strict=strict).wave_ops()
+    return yee.mag_wave_modes(o, deck.params["eigensolver : shift"], want)
+
+
+def _sparse_physical_modes(deck, want):
+    """For decks too large for the dense restatement (D-M frac 0 only): divergence-free modes of the
+    oracle-assembled pencil by sparse shift-invert, as tests/test_eigen_gpu.py does."""
+    o = deck.sim().wave_ops()
+    L, M, D = o["vecLapl"], o["mRhs"], o["divB"]
+    d = M.diagonal(); keep = d > 0
+    vals, vecs = spla.eigsh(L[keep][:, keep].tocsc(), k=4 * want + 6, M=sp.diags(d[keep]).tocsc(),
+                            sigma=deck.params["eigensolver : shift"] - 1e-3, which="LM", tol=1e-13)
+    out = []
+    for lam, v in zip(vals, vecs.T):
+        full = np.zeros(L.shape[0]); full[keep] = v
+        if np.linalg.norm(D @ (M @ full)) / np.linalg.norm(full) < 1e-6:
+            out.append(lam)
+    return np.sort(out)[:want]
+
+
+def _vacuum_modes(deck, want):
+    """Periodic vacuum: the exact discrete spectrum sum_i (2/h_i sin(pi m_i/N_i))^2, two
+    polarisations per non-zero wave vector, three constant fields at k^2 = 0 (in a degenerate
+    eigenspace longitudinal and transverse fields mix, so a divergence filter cannot be used)."""
+    n, size = np.array(deck.n), np.array(deck.size)
+    h = size / n
+    vals = [0.0, 0.0, 0.0]
+    for m in np.ndindex(*n):
+        if any(m):
+            vals += [float(np.sum((2.0 / h * np.sin(np.pi * np.array(m) / n)) ** 2))] * 2
+    return np.sort(vals)[:want]
+
+
+def test_maxwell_cli_pillbox_deck(built, tmp_path):
+    """`maxwell --infile=pillbox.mx`: prints the table of src/MxSolver.cpp:176-196; TM010 and a TE111 copy."""
+    deck = mxdeck.load(os.path.join(GOLDEN, "pillbox.mx"))
+    want = _sparse_physical_modes(deck, 3)   # TM010, TE111 x2 (the pair is degenerate: either copy is fine)
+    eig = tmp_path / "eig.txt"
+    r = subprocess.run([CLI, "--infile=" + os.path.join(GOLDEN, "pillbox.mx"), "--eigvals=" + str(eig)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Running simulation: Simulation" in r.stdout
+    assert "========= Eigenfrequencies (Hz) =========" in r.stdout
+    rows = re.findall(r"^\s*(\d+):\s+(\S+)\s+(\S+)\s+(\S+)\s*$", r.stdout, flags=re.M)
+    assert len(rows) == 2
+    table = np.array([[float(x) for x in row[1:]] for row in rows])
+    saved = np.loadtxt(str(eig), ndmin=2)
+    assert np.allclose(saved[:, 1], table[:, 0], rtol=1e-8)          # table prints 9 significant digits
+    k2 = np.sort((2 * np.pi * saved[:, 1] / C0) ** 2)
+    assert abs(k2[0] - want[0]) / want[0] < 1e-5, (k2, want)
+    assert abs(k2[1] - want[1]) / want[1] < 1e-5, (k2, want)
+    assert np.all(saved[:, 2] == 0.0) and np.all(saved[:, 3] < 1e-4)
+    tm010 = (2.404825557695773 / 0.4) ** 2
+    assert abs(k2[0] - tm010) / tm010 < 6e-3                           # O(h^2) at resolution 18
+
+
+def test_maxwell_cli_errors(built, tmp_path):
+    r = subprocess.run([CLI], capture_output=True, text=True, timeout=60)
+    assert "Please specify an input file using --infile=your_file.mx" in r.stdout
+    bad = tmp_path / "bad.mx"
+    bad.write_text("<S>\n polarization = TE\n <Mu>\n </Mu>\n</S>\n")
+    r = subprocess.run([CLI, "--infile=" + str(bad)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "<Mu>" in r.stdout
+
+
+@pytest.mark.parametrize("name,nmodes", [("vacuum.mx", 5), ("tilted_cavity.mx", 3)])
+def test_deck_through_the_c_abi(ctx, name, nmodes):
+    """mxh_problem_solver: deck parameters drive MxSolver; eigenvalues against the oracle pencil."""
+    deck = mxdeck.load(os.path.join(GOLDEN, name))
+    prob = mx.Problem(path=os.path.join(GOLDEN, name))
+    solver = prob.solver(ctx)
+    assert solver.solve() == nmodes
+    k2 = np.sort([solver.result(i)["k2"].real for i in range(nmodes)])
+    want = _oracle_modes(deck, nmodes)
+    tol = 50 * deck.params["eigensolver : tol"]
+    assert np.abs(k2 - want).max() / np.abs(want).max() < tol, (k2, want)
+
+
+def test_periodic_vacuum_deck_exact_spectrum(ctx):
+    """Same deck without the reference's periodic-wrap quirk (strict=False): the exact discrete spectrum."""
+    name = os.path.join(GOLDEN, "vacuum.mx")
+    deck = mxdeck.load(name)
+    solver = mx.Problem(path=name, strict=False).solver(ctx)
+    assert solver.solve() == 5
+    k2 = np.sort([solver.result(i)["k2"].real for i in range(5)])
+    want = _vacuum_modes(deck, 5)
+    assert np.abs(k2 - want).max() / want.max() < 50 * deck.params["eigensolver : tol"], (k2, want)

@@ -1,0 +1,136 @@
+"""`.mx` input decks: the C++ reader (include/mx/MxProblem.h via mxh_problem_*) against the
+independent Python restatement oracle/mxdeck.py, on hand-written decks (tests/golden/*.mx; see the
+comment at the top of each deck and DESIGN.md §5: not output of the reference's writer).
+
+CPU-only: parsing and assembly need no GPU.  The GPU end-to-end run is tests/test_mx_cli_gpu.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import maxwell_amd as mx
+from oracle import mxdeck
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+pytestmark = pytest.mark.usefixtures("built")
+DECKS = ["pillbox.mx", "vacuum.mx", "tilted_cavity.mx"]
+
+
+def _text(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return f.read()
+
+
+def _same_number(a, b):
+    return float(a) == float(b)
+
+
+@pytest.mark.parametrize("name", DECKS)
+def test_parameters_match_restatement(built, name):
+    """Every parameter-list entry (src/MxProblem.cpp:82-105 keys), grid and BCs agree."""
+    deck = mxdeck.Deck(_text(name))
+    prob = mx.Problem(path=os.path.join(GOLDEN, name))
+    g = prob.grid()
+    assert g["n"] == deck.n and g["origin"] == deck.origin and g["size"] == deck.size
+    assert g["lower"] == deck.lower and g["upper"] == deck.upper
+    assert g["dm_frac"] == deck.dm_frac and g["has_pec"] == (deck.pec is not None)
+    for key, val in deck.params.items():
+        got = prob.param(key)
+        if isinstance(val, bool):
+            assert got == ("1" if val else "0"), key
+        elif isinstance(val, (int, float)):
+            assert _same_number(got, val), (key, got, val)
+        else:
+            assert got == val, key
+
+
+def test_defaults_of_the_reference_tables():
+    """A deck with nothing but the polarization takes the defaults of src/MxProblem.cpp:26-66,445-459,604-612."""
+    prob = mx.Problem(text="<Sim>\n polarization = TE\n</Sim>")
+    assert prob.grid() == dict(n=[16] * 3, origin=[0.0] * 3, size=[1.0] * 3, lower=["periodic"] * 3,
+                               upper=["periodic"] * 3, dm_frac=0.0, has_pec=False)
+    expect = {"eigensolver : type": "krylov-schur", "eigensolver : basis": "20", "eigensolver : max restarts": "100",
+              "eigensolver : invert": "1", "eigensolver : block size": "1", "eigensolver : nev": "10",
+              "eigensolver : spectrum": "LM", "eigensolver : output": "2", "linear solver : type": "gmres",
+              "linear solver : basis": "40"}
+    for k, v in expect.items():
+        assert prob.param(k) == v, k
+    assert float(prob.param("eigensolver : tol")) == 1.0e-6
+    assert float(prob.param("linear solver : tol")) == 1.0e-6
+    with pytest.raises(KeyError):
+        prob.param("linear solver : prec type")
+
+
+def test_body_line_wins_over_tag_attribute():
+    """MxUtil::XML::getAttr: body first, then tag attribute (src/MxUtil.cpp:266-280)."""
+    prob = mx.Problem(text='<S polarization="TM">\n <Eigensolver nev="4">\n  nev = 7\n  <LinearSolver/>\n'
+                           ' </Eigensolver>\n</S>')
+    assert prob.param("eigensolver : nev") == "7"
+    assert prob.param("polarization") == "TM"
+
+
+@pytest.mark.parametrize("text,needle", [
+    ("<S>\n</S>", "polarization"),                                              # required attribute
+    ("<S>\n polarization = XX\n</S>", "Invalid polarization"),
+    ("<S>\n polarization = TE\n <Eigensolver>\n nev = 2\n </Eigensolver>\n</S>", "LinearSolver"),
+    ("<S>\n polarization = TE\n <BoundaryConditions>\n lower bcs = [pec, foo, pec]\n </BoundaryConditions>\n</S>",
+     "Invalid lower boundary condition"),
+    ("<S>\n polarization = TE\n <Dielectric>\n </Dielectric>\n</S>", "Dielectric"),
+    ("<S>\n polarization = TE\n <PEC>\n <Torus>\n name = t\n </Torus>\n </PEC>\n</S>", "Torus"),
+    ("<S>\n polarization = TE\n <Eigensolver>\n <LinearSolver>\n <Preconditioner>\n type = foo\n </Preconditioner>\n"
+     " </LinearSolver>\n </Eigensolver>\n</S>", "Preconditioner type"),
+    ("<S>\n polarization = TE\n <BoundaryConditions>\n phase shifts = [0.1, 0, 0]\n </BoundaryConditions>\n</S>",
+     "phase shifts"),
+    ("<S>\n polarization = TE\n <Grid>\n</S>", "parse error"),
+    ("<S>\n polarization = TE\n", "parse error"),
+])
+def test_errors_are_reported(text, needle):
+    with pytest.raises(mx.MxError) as e:
+        mx.Problem(text=text)
+    assert needle in str(e.value)
+
+
+@pytest.mark.parametrize("name", ["pillbox.mx", "tilted_cavity.mx"])
+def test_pec_level_set_bit_identical(name):
+    """Shape factory + transforms in document order: the level set equals the restatement's bit for bit."""
+    deck = mxdeck.Deck(_text(name))
+    prob = mx.Problem(text=_text(name))
+    rng = np.random.default_rng(7)
+    lo = np.array(deck.origin)
+    pts = lo + rng.random((400, 3)) * np.array(deck.size)
+    want = deck.pec.func(pts)
+    got = np.array([prob.pec_func(p) for p in pts])
+    assert np.array_equal(got, want)
+    assert (want > 0).any() and (want < 0).any()
+
+
+@pytest.mark.parametrize("name", DECKS)
+def test_assembled_operators_bit_identical(name):
+    """Deck -> assembled operators: C++ (mxh_problem_sim) == oracle (Deck.sim), values and pattern."""
+    deck = mxdeck.Deck(_text(name))
+    osim = deck.sim()
+    ops = osim.wave_ops()
+    sim = mx.Problem(text=_text(name)).sim()
+    for field in ("bfield", "efield", "psifield"):
+        want = {"bfield": osim.B, "efield": osim.E, "psifield": osim.P}[field].gids
+        assert np.array_equal(sim.map(field), want), field
+    for opname, ref in ops.items():
+        a, b = sim.op(opname).tocsr(), ref.tocsr()
+        a.sort_indices(); b.sort_indices()
+        d = a - b            # the product keeps explicit zeros (as Epetra does): compare on the union pattern
+        assert a.shape == b.shape and (d.nnz == 0 or np.abs(d.data).max() == 0.0), opname
+
+
+def test_dm_frac_zeroes_small_faces():
+    """<PEC> 'D-M frac' (src/MxYeeFitBField.cpp:83-90): B faces below the threshold get factor 0 -
+    the map is unchanged, curlE rows of those faces vanish."""
+    base = _text("tilted_cavity.mx")
+    a = mx.Problem(text=base.replace("D-M frac = 0.05", "D-M frac = 0.0")).sim()
+    b = mx.Problem(text=base).sim()
+    assert np.array_equal(a.map("bfield"), b.map("bfield"))
+    ca, cb = a.op("curlE"), b.op("curlE")
+    rows_a = np.diff(ca.indptr) > 0
+    rows_b = np.abs(cb).sum(axis=1).A1 > 0
+    assert rows_b.sum() < (np.abs(ca).sum(axis=1).A1 > 0).sum()
+    assert not (rows_b & ~rows_a).any()
