@@ -17,18 +17,22 @@
 int main(int argc, char* argv[]) {
   std::string inFile, eigFile;
   int device = 0;
+  bool strict = true;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a.compare(0, 9, "--infile=") == 0) inFile = a.substr(9);
     else if (a == "--infile" && i + 1 < argc) inFile = argv[++i];
     else if (a.compare(0, 10, "--eigvals=") == 0) eigFile = a.substr(10);
     else if (a.compare(0, 9, "--device=") == 0) device = atoi(a.substr(9).c_str());
+    else if (a == "--fix-periodic-wrap") strict = false;
     else if (a == "--help" || a == "-h") {
       std::cout << "Usage: " << argv[0] << " [options]\n  options:\n"
                 << "  --help               Prints this help message\n"
                 << "  --infile    string   XML format input file.\n"
                 << "  --eigvals   string   write 'index real imag error' lines of the eigenfrequencies (Hz)\n"
-                << "  --device    int      GPU ordinal (default 0)\n";
+                << "  --device    int      GPU ordinal (default 0)\n"
+                << "  --fix-periodic-wrap  keep the wrap-around entries the reference drops from curlE on\n"
+                << "                       periodic axes (DESIGN.md section 7); default: reference behaviour\n";
       return 0;
     } else {
       std::cout << "Unrecognised option: " << a << "\n";
@@ -57,7 +61,7 @@ int main(int argc, char* argv[]) {
     }
     RCP<MxComm> myComm = rcp(new MxComm(device));
     {
-      MxProblem<3> prob3d(xmlObj, myComm);
+      MxProblem<3> prob3d(xmlObj, myComm, strict);
       prob3d.solve();
       if (eigFile != "") {
         std::ofstream out(eigFile.c_str());
