@@ -488,7 +488,8 @@ template <typename CFG, int CH, bool DOT = false>
 __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
     const BlkDesc* __restrict__ desc, long long nblocks, const long long* __restrict__ rowptr,
     const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y,
-    const double* __restrict__ xdot = nullptr, double* __restrict__ partial = nullptr) {
+    const double* __restrict__ xdot = nullptr, double* __restrict__ partial = nullptr,
+    const unsigned short* __restrict__ roff = nullptr) {
   constexpr int SB = CFG::SBLK, EPT = CFG::EPT;
   __shared__ double sval[CFG::NNZ_BLK];
   __shared__ int scol[CFG::NNZ_BLK];
@@ -529,8 +530,15 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
   }
   int o0 = 0, o1 = 0;
   if ((int)threadIdx.x < d.nr) {
-    o0 = (int)(nt_load(rowptr + d.r0 + threadIdx.x) - d.base);
-    o1 = (int)(nt_load(rowptr + d.r0 + threadIdx.x + 1) - d.base);
+    if (roff) {
+      // 16-bit in-block row offsets (rowptr[r] - base, block b starts at r0 + b): 2 B/row instead of 8
+      const unsigned short* ro = roff + d.r0 + b + threadIdx.x;
+      o0 = ro[0];
+      o1 = ro[1];
+    } else {
+      o0 = (int)(nt_load(rowptr + d.r0 + threadIdx.x) - d.base);
+      o1 = (int)(nt_load(rowptr + d.r0 + threadIdx.x + 1) - d.base);
+    }
   }
   __syncthreads();
   for (int j = 0; j < X.k; ++j) {
@@ -654,7 +662,7 @@ void launch_stream(mxg_ctx* c, const mxg_csr* a, const MvDesc& X, const MvDesc& 
 template <typename CFG>
 static int build_xwin(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx);
 static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr);
-constexpr int MXG_KERNEL_DEFAULT = 0x710000;
+constexpr int MXG_KERNEL_DEFAULT = 0x750000;   // row-gather 2048 nnz, gather chunk 7, 16-bit in-block row offsets
 
 extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, int64_t nghost,
                               const int64_t* rowptr, const int32_t* colidx, const double* vals,
@@ -745,6 +753,7 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   hipFree(a->d_diag);
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
   if (a->d_dotpartial) hipFree(a->d_dotpartial);
+  if (a->d_roff) hipFree(a->d_roff);
   if (a->d_xwdesc) hipFree(a->d_xwdesc);
   if (a->d_lcol) hipFree(a->d_lcol);
   if (a->d_send_idx) hipFree(a->d_send_idx);
@@ -901,6 +910,21 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
   }
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
   if (a->d_dotpartial) { hipFree(a->d_dotpartial); a->d_dotpartial = nullptr; }
+  if (a->d_roff) { hipFree(a->d_roff); a->d_roff = nullptr; }
+  if (geo >= 10) {
+    // row-gather kernel: in-block row offsets as uint16 (nr + 1 per block, block b at r0 + b);
+    // blocks holding one over-long row take the whole-workgroup path and never read them
+    std::vector<unsigned short> roff((size_t)a->nrows + desc.size() + 1, 0);
+    for (size_t b = 0; b < desc.size(); ++b) {
+      const BlkDesc& d = desc[b];
+      if (d.nnzb > cap) continue;
+      for (int r = 0; r <= d.nr; ++r) roff[(size_t)d.r0 + b + r] = (unsigned short)(host_rowptr[d.r0 + r] - d.base);
+    }
+    MXG_HIP(hipMalloc(&a->d_roff, sizeof(unsigned short) * roff.size()));
+    MXG_HIP(hipMemcpyAsync(a->d_roff, roff.data(), sizeof(unsigned short) * roff.size(), hipMemcpyHostToDevice,
+                           c->stream));
+    MXG_HIP(hipStreamSynchronize(c->stream));
+  }
   MXG_HIP(hipMalloc(&a->d_blkdesc, sizeof(BlkDesc) * std::max<size_t>(desc.size(), 1)));
   if (!desc.empty())
     MXG_HIP(hipMemcpyAsync(a->d_blkdesc, desc.data(), sizeof(BlkDesc) * desc.size(),
@@ -1033,7 +1057,8 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
 #define MXG_RG(CFG, CHV)                                                                           \
     hipLaunchKernelGGL((k_spmv_rowgather<CFG, CHV>), dim3(grid), dim3(CFG::SBLK), 0, c->stream,       \
                        (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr, \
-                       a->d_colidx, a->d_vals, X, Y)
+                       a->d_colidx, a->d_vals, X, Y, (const double*)nullptr, (double*)nullptr,       \
+                       (a->kernel & 0x40000) ? (const unsigned short*)a->d_roff : (const unsigned short*)nullptr)
     if (a->pipe_geo == 10) { if (ch == 4) MXG_RG(RgCfgA, 4); else if (ch == 7) MXG_RG(RgCfgA, 7); else MXG_RG(RgCfgA, 8); }
     else { if (ch == 4) MXG_RG(RgCfgB, 4); else if (ch == 7) MXG_RG(RgCfgB, 7); else MXG_RG(RgCfgB, 8); }
 #undef MXG_RG
@@ -1111,7 +1136,8 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
   (void)hipGetLastError();
   hipLaunchKernelGGL((k_spmv_rowgather<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,
                      (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr,
-                     a->d_colidx, a->d_vals, X, Y, (const double*)x->colptr(0), a->d_dotpartial);
+                     a->d_colidx, a->d_vals, X, Y, (const double*)x->colptr(0), a->d_dotpartial,
+                     (a->kernel & 0x40000) ? (const unsigned short*)a->d_roff : (const unsigned short*)nullptr);
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, (const double*)a->d_dotpartial,
                      (long long)a->npipe, d_out);
   MXG_HIP(hipGetLastError());

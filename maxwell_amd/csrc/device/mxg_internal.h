@@ -126,6 +126,7 @@ struct mxg_csr {
   int64_t npipe = 0;
   int pipe_geo = -1;
   double* d_dotpartial = nullptr;   // per-block partials of the fused SpMV + dot
+  unsigned short* d_roff = nullptr; // row-gather kernel: 16-bit in-block row offsets (nrows + nblocks + 1)
   // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
   void* d_xwdesc = nullptr;
   unsigned short* d_lcol = nullptr;

@@ -156,7 +156,7 @@ def test_full_size_linearity_and_constant_nullspace(ctx):
     assert p.norm2()[0] < 1e-9 * b.norm2()[0]
 
 
-@pytest.mark.parametrize("code", [0x10000, 0x20000, 0x710000, 0x410000, 0x4000, 0x8000, 0x0, 0x2, 0x4, 0x10, 0x20, 0x30, 0x540, 0x840, 0x480, 0x180, 0x1])
+@pytest.mark.parametrize("code", [0x10000, 0x20000, 0x710000, 0x750000, 0x460000, 0x410000, 0x4000, 0x8000, 0x0, 0x2, 0x4, 0x10, 0x20, 0x30, 0x540, 0x840, 0x480, 0x180, 0x1])
 def test_every_kernel_variant_bit_exact(ctx, oracle_pillbox16, rng, code):
     """All tuning variants (plain / non-temporal loads, XCD remap, block geometries, the
     software-pipelined persistent kernel) must give the same bits as the serial row loop;
