@@ -14,7 +14,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("case,world", [("pillbox", 2), ("periodic", 2), ("pillbox", 4)])
+@pytest.mark.parametrize("case,world", [("pillbox", 2), ("periodic", 2), ("pillbox", 4), ("pillbox", 8)])
 def test_box_assembly_and_halo_plan_gloo(built, case, world):
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
