@@ -50,7 +50,8 @@ class _Field:
         self.dirs = dirs          # component direction (None for psi)
         self.lbc = np.zeros((ncomp, 3), dtype=int)
         self.ubc = np.zeros((ncomp, 3), dtype=int)
-        self.frac = None          # list over comps of ext-lattice arrays, or None (no region)
+        self.frac = None          # region ('pec') fractions: list over comps of ext-lattice arrays, or None
+        self.reps = {}            # other shape reps by name (dielectrics): same layout, not a region
         self.gids = None          # sorted global ids in the map
         self.comp = None
         self.cells = None
@@ -61,7 +62,7 @@ class YeeSim:
 
     def __init__(self, N, origin=(0., 0., 0.), size=(1., 1., 1.),
                  lower=("periodic",) * 3, upper=("periodic",) * 3,
-                 pec=None, phase_shifts=(0., 0., 0.), strict=True, dm_frac=0.0):
+                 pec=None, phase_shifts=(0., 0., 0.), strict=True, dm_frac=0.0, dielectrics=()):
         self.n = np.array([int(N)] * 3 if np.isscalar(N) else [int(x) for x in N])
         self.origin = np.array(origin, dtype=float)
         self.size = np.array(size, dtype=float)
@@ -79,7 +80,13 @@ class YeeSim:
         E = _Field("efield", 3, np.array([[half, 0, 0], [0, half, 0], [0, 0, half]]), [0, 1, 2])
         P = _Field("psifield", 1, np.array([[half, half, half]]), [None])
         self.B, self.E, self.P = B, E, P
-        for F, normal_pec, tang_pec in ((B, ZERO, CONSTANT), (E, CONSTANT, ZERO)):
+        # dielectrics: (shape, 3x3 real symmetric eps, name), src/MxProblem.cpp:487-527 / MxDielectric.cpp
+        self.dielectrics = [(sh, np.array(eps, dtype=float).reshape(3, 3), name) for sh, eps, name in dielectrics]
+        # D lives where E lives (MxYeeElecFieldBase) but is represented by the dual face
+        # (src/MxYeeFitDField.cpp:42-52); only built with dielectrics (src/MxEMSim.cpp:83-88)
+        D = _Field("dfield", 3, E.coords.copy(), [0, 1, 2]) if self.dielectrics else None
+        self.D = D
+        for F, normal_pec, tang_pec in ((B, ZERO, CONSTANT), (E, CONSTANT, ZERO)) + (((D, CONSTANT, ZERO),) if D else ()):
             for c in range(3):
                 for i in range(3):
                     for bcs, arr in ((lower, F.lbc), (upper, F.ubc)):
@@ -93,11 +100,18 @@ class YeeSim:
             for bcs, arr in ((lower, P.lbc), (upper, P.ubc)):
                 arr[0, i] = {"pec": CONSTANT, "pmc": ZERO, "periodic": PERIODIC}[bcs[i]]
 
+        fields = [F for F in (B, E, D, P) if F is not None]
         if pec is not None:
-            for F in (B, E, P):
-                self._add_shape_rep(F, pec)
+            for F in fields:
+                F.frac = self._add_shape_rep(F, pec)            # src/MxEMSim.cpp:121-129 (region)
+        for sh, _, name in self.dielectrics:                    # src/MxEMSim.cpp:131-146 (not on B)
+            for F in fields:
+                if F is not B:
+                    F.reps[name] = self._add_shape_rep(F, sh)
         for F in (B, E, P):
             self._set_map(F)
+        if D is not None:                                       # dfield->setMap(efield), src/MxEMSim.cpp:196-197
+            D.gids, D.comp, D.cells = E.gids, E.comp, E.cells
 
     # ---------------------------------------------------------------- lattice helpers
     def node_coord(self, cells):
@@ -151,11 +165,12 @@ class YeeSim:
     def comp_coord(self, F, comp, cells):
         return self.node_coord(cells) + F.coords[comp] * self.d
 
-    def frac_at(self, F, comp, cells):
-        """getCompFrac, src/MxGridField.hpp:258-277: one guard cell, 1.0 without a region."""
-        if F.frac is None:
+    def frac_at(self, F, comp, cells, name=None):
+        """getCompFrac, src/MxGridField.hpp:258-277: one guard cell, 1.0 without that shape rep."""
+        rep = F.frac if name is None else F.reps.get(name)
+        if rep is None:
             return np.ones(cells.shape[:-1])
-        return F.frac[comp][cells[..., 0] + 1, cells[..., 1] + 1, cells[..., 2] + 1]
+        return rep[comp][cells[..., 0] + 1, cells[..., 1] + 1, cells[..., 2] + 1]
 
     def _ext_cells(self):
         ax = [np.arange(-1, self.n[i] + 2) for i in range(3)]
@@ -166,17 +181,18 @@ class YeeSim:
         """addShapeRep with one guard cell, src/MxGridField.cpp:193-226."""
         cells = self._ext_cells()
         ext_shape = tuple(self.n + 3)
-        F.frac = []
+        out = []
         for comp in range(F.ncomp):
             pos = self.comp_coord(F, comp, self.interior(F, comp, cells))
-            if F is self.B:
+            if F is self.B or F is self.D:      # face / dual face normal to the component
                 c1, c2 = (comp + 1) % 3, (comp + 2) % 3
                 fr = geo.rect_fractions(shape, pos, comp, self.d[c1], self.d[c2])
             elif F is self.E:
                 fr = geo.segment_fractions(shape, pos, comp, self.d[comp])
             else:
                 fr = geo.box_fractions(shape, pos, self.d[0], self.d[1], self.d[2])
-            F.frac.append(fr.reshape(ext_shape))
+            out.append(fr.reshape(ext_shape))
+        return out
 
     # ---------------------------------------------------------------- membership / factors
     def base_use(self, F, comp, cells):
@@ -268,6 +284,8 @@ class YeeSim:
             # MxYeeFitBField::getCompFactor, src/MxYeeFitBField.cpp:83-90
             if F.frac is not None and self.dm_frac > 0.0:
                 res = np.where(self.frac_at(F, comp, cells) < self.dm_frac, 0.0, res)
+            return res
+        if F is self.D:                       # no override: MxGridField::getCompFactor
             return res
         probe = cells if self.strict else self.interior(F, comp, cells)
         return np.where(self.use(F, comp, probe), res, 0.0)
@@ -386,6 +404,166 @@ class YeeSim:
             out[s] = self.frac_at(F, c, F.cells[s])
         return out
 
+
+    # ---------------------------------------------------------------- FIT inverse permittivity
+    @staticmethod
+    def _eps_is_diag(eps):
+        """MxDielectric::checkIsDiag, src/MxDielectric.cpp:25-34 (MxUtil::dEps = 0: any non-zero upper-triangle entry)."""
+        return not (abs(eps[0, 1]) > 0.0 or abs(eps[0, 2]) > 0.0 or abs(eps[1, 2]) > 0.0)
+
+    @staticmethod
+    def _gamma_pi(eps, n):
+        """gamma = I + n n^T (I - eps) / (n . eps n), pi = eps gamma (src/MxYeeFitInvEps.cpp:345-347,365-366);
+        plain float loops in a fixed order so that the host code can match bit for bit."""
+        epsn = [eps[i][0] * n[0] + eps[i][1] * n[1] + eps[i][2] * n[2] for i in range(3)]
+        denom = n[0] * epsn[0] + n[1] * epsn[1] + n[2] * epsn[2]
+        ime = [[(1.0 if i == j else 0.0) - eps[i][j] for j in range(3)] for i in range(3)]
+        nn = [[n[i] * n[j] for j in range(3)] for i in range(3)]
+        prod = geo._matmul3(nn, ime)
+        gamma = [[(1.0 if i == j else 0.0) + prod[i][j] / denom for j in range(3)] for i in range(3)]
+        pi = geo._matmul3(eps, gamma)
+        return gamma, pi
+
+    def _tuple_update(self, comps, cells, normal):
+        """tupleUpdate, src/MxYeeFitInvEps.cpp:305-385: length-fraction weighted rows of gamma times the
+        inverse of area-fraction weighted rows of pi, over the dielectrics and the background."""
+        ave_g = [[0.0] * 3 for _ in range(3)]
+        ave_p = [[0.0] * 3 for _ in range(3)]
+        lsum, asum = [0.0] * 3, [0.0] * 3
+        bg = [[1.0 if i == j else 0.0 for j in range(3)] for i in range(3)]
+        for sh, eps, name in self.dielectrics:
+            lf, af = [0.0] * 3, [0.0] * 3
+            for j in range(3):
+                c = comps[j]
+                cell = np.array(cells[j])
+                lf[c] = float(self.frac_at(self.E, c, cell, name))
+                af[c] = float(self.frac_at(self.D, c, cell, name))
+                lsum[c] += lf[c]
+                asum[c] += af[c]
+            gamma, pi = self._gamma_pi(eps.tolist(), normal)
+            for j in range(3):
+                for k in range(3):
+                    ave_g[j][k] += lf[j] * gamma[j][k]
+                    ave_p[j][k] += af[j] * pi[j][k]
+        gamma, pi = self._gamma_pi(bg, normal)
+        for j in range(3):
+            lfj, afj = 1.0 - lsum[j], 1.0 - asum[j]
+            for k in range(3):
+                ave_g[j][k] += lfj * gamma[j][k]
+                ave_p[j][k] += afj * pi[j][k]
+        return geo._matmul3(ave_g, geo._inverse3(ave_p))
+
+    def inv_eps(self):
+        """MxYeeFitInvEps::setMatrix, src/MxYeeFitInvEps.cpp:421-560 (3-D, real eps, no PML): rows
+        and columns on the E map; 1/eps_cc on rows wholly inside one (diagonal) material, otherwise
+        the 9-point stencil averaged over the admissible tuples.  Entries whose column is not in
+        the map are left out (Epetra never imports a value for them)."""
+        E, D = self.E, self.D
+        rows, cols, vals = [], [], []
+        tuple_inds = [(0, 1, 5), (0, 1, 6), (0, 2, 5), (0, 2, 6), (0, 3, 7), (0, 3, 8), (0, 4, 7), (0, 4, 8)]
+        names = [name for _, _, name in self.dielectrics]
+        lf0 = {nm: np.empty(len(E.gids)) for nm in names}
+        af0 = {nm: np.empty(len(E.gids)) for nm in names}
+        for c in range(3):
+            sel = E.comp == c
+            for nm in names:
+                lf0[nm][sel] = self.frac_at(E, c, E.cells[sel], nm)
+                af0[nm][sel] = self.frac_at(D, c, E.cells[sel], nm)
+        for r in range(len(E.gids)):
+            comp0 = int(E.comp[r]); cell = E.cells[r]
+            in_diel, eps_diag, eps_here = False, False, None
+            for sh, eps, nm in self.dielectrics:                       # :462-479
+                l0, a0 = lf0[nm][r], af0[nm][r]
+                if l0 == 1 and a0 == 1:
+                    in_diel, eps_diag, eps_here = True, self._eps_is_diag(eps), eps
+                    break
+                elif l0 == 0 and a0 == 0:
+                    continue
+                else:
+                    in_diel = True
+                    break
+            if not in_diel:
+                eps_diag, eps_here = True, np.eye(3)
+            if eps_diag:                                                # :505-512
+                fac = self.factor(D, comp0, cell[None, :])[0]
+                rows.append(r); cols.append(r); vals.append((fac / eps_here[comp0, comp0]).real)
+                continue
+            comp1, comp2 = (comp0 + 1) % 3, (comp0 + 2) % 3            # getStencil, :35-71
+            scomps = [comp0] + [comp1] * 4 + [comp2] * 4
+            scells = [cell.copy() for _ in range(9)]
+            scells[1][comp1] -= 1
+            scells[3][comp0] += 1; scells[3][comp1] -= 1
+            scells[4][comp0] += 1
+            scells[5][comp2] -= 1
+            scells[7][comp0] += 1; scells[7][comp2] -= 1
+            scells[8][comp0] += 1
+            normal = self._stencil_normal(comp0, cell, scomps, scells)
+            tuples = []                                                 # getTuples, :127-175
+            for t in tuple_inds:
+                ok = True
+                if self.pec is not None:
+                    for si in t:
+                        if float(self.frac_at(E, scomps[si], scells[si])) == 0:
+                            ok = False
+                if ok:
+                    tuples.append(t)
+            svals = [0.0] * 9
+            nt = float(len(tuples))
+            for t in tuples:                                            # :519-531
+                m = self._tuple_update([scomps[si] for si in t], [scells[si] for si in t], normal)
+                for si in t:
+                    svals[si] += m[comp0][scomps[si]] / nt
+            for si in range(9):                                         # :533-537
+                fac = self.factor(D, scomps[si], scells[si][None, :])[0].real
+                g = self.gid(D, scomps[si], scells[si][None, :])
+                pos, ok = self.lid(D, g)
+                if ok[0]:
+                    rows.append(r); cols.append(int(pos[0])); vals.append(svals[si] * fac)
+        n = len(E.gids)
+        m = sp.coo_matrix((np.array(vals, dtype=float), (rows, cols)), shape=(n, n)).tocsr()
+        m.sum_duplicates(); m.sort_indices()
+        return m
+
+    def _stencil_normal(self, comp0, cell, scomps, scells):
+        """getNormal, src/MxYeeFitInvEps.cpp:254-302: the (sign-aligned, summed, normalised) interface
+        normals of the dielectrics that cut any member of the stencil, taken at the row's edge centre."""
+        import math
+        norms = []
+        coord = self.comp_coord(self.E, comp0, cell)
+        for sh, eps, nm in self.dielectrics:
+            cut = False
+            for c, cl in zip(scomps, scells):
+                lf = float(self.frac_at(self.E, c, cl, nm)); af = float(self.frac_at(self.D, c, cl, nm))
+                if (lf != 0 and lf != 1) or (af != 0 and af != 1):
+                    cut = True
+            if cut:
+                g = sh.grad1((float(coord[0]), float(coord[1]), float(coord[2])))
+                nn = math.sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2])
+                norms.append([g[0] / nn, g[1] / nn, g[2] / nn])
+        if not norms:
+            return [1.0, 0.0, 0.0]
+        tot = [0.0, 0.0, 0.0]
+        for i, v in enumerate(norms):
+            sgn = 1.0
+            if i > 0 and (norms[0][0] * v[0] + norms[0][1] * v[1] + norms[0][2] * v[2]) < 0:
+                sgn = -1.0
+            for k in range(3):
+                tot[k] += sgn * v[k]
+        nn = math.sqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2])
+        return [tot[0] / nn, tot[1] / nn, tot[2] / nn]
+
+    def inv_eps_vol_ave(self):
+        """cellAveInvEpsOperator, src/MxYeeFitInvEps.cpp:700-790: volume-fraction average of
+        3/trace(eps) on the Psi map (diagonal)."""
+        P = self.P
+        out = np.zeros(len(P.gids)); sums = np.zeros(len(P.gids))
+        for sh, eps, nm in self.dielectrics:
+            fr = self.frac_at(P, 0, P.cells, nm)
+            sums = sums + fr
+            out = out + fr * (3.0 / (eps[0, 0] + eps[1, 1] + eps[2, 2]))
+        out = out + (1.0 - sums) * (3.0 / 3.0)
+        return sp.diags(out, format="csr")
+
     # ---------------------------------------------------------------- MxMagWaveOp matrices
     def single_ops(self):
         """MxEMOps::setSingleOps, src/MxEMOps.cpp:39-168 (vacuum / PEC subset)."""
@@ -395,6 +573,9 @@ class YeeSim:
             ops["dmA"] = self.fracs(self.B)
             ops["dmL"] = self.fracs(self.E)
             ops["dmVInv"] = self.fracs(self.P, inverse=True)
+        if self.dielectrics:                                   # src/MxEMOps.cpp:66-77
+            ops["invEps"] = self.inv_eps()
+            ops["invEpsVolAve"] = self.inv_eps_vol_ave()
         return ops
 
     @staticmethod
@@ -414,8 +595,10 @@ class YeeSim:
         o = self.single_ops()
         has_pec = self.pec is not None
         pec = lambda name: [name] if has_pec else []
-        curlcurl = self.multiply_ops(o, ["curlB"] + pec("dmL") + ["curlE"])                 # :145-153
-        graddiv = self.multiply_ops(o, pec("dmA") + ["divB"] + pec("dmVInv") + ["gradPsi"] + pec("dmA"))  # :156-179
+        diel = lambda name: [name] if self.dielectrics else []
+        curlcurl = self.multiply_ops(o, ["curlB"] + diel("invEps") + pec("dmL") + ["curlE"])   # :145-153
+        graddiv = self.multiply_ops(o, pec("dmA") + ["divB"] + pec("dmVInv") + diel("invEpsVolAve") +
+                                    ["gradPsi"] + pec("dmA"))                                 # :156-179
         scalapl = -self.multiply_ops(o, ["gradPsi"] + pec("dmA") + ["divB"])                # :208-220
         if has_pec:
             rhs = o["dmA"]                                                                  # :233-236
