@@ -34,6 +34,15 @@ const char* mxh_last_error(void);
 int mxh_sim_create(const int n[3], const double origin[3], const double size[3],
                    const char* const lower[3], const char* const upper[3], const char* pec_shape,
                    int strict, mxh_sim** out);
+/* mxh_sim_create_box plus materials: `dielectrics` = "e11,e22,e33[,o0,o1,o2] : shape-spec | ..." (real
+ * symmetric permittivity tensors in the deck's `eps diag` / `eps off diag` order, src/MxProblem.cpp:487-527;
+ * background vacuum), `dm_frac` = the <PEC> block's D-M frac.  With dielectrics the operator list gains
+ * invEps (FIT inverse permittivity, src/MxYeeFitInvEps.cpp) and invEpsVolAve, and curlCurl / gradDiv
+ * include them (src/MxMagWaveOp.cpp:140-179). */
+int mxh_sim_create_ex(const int n[3], const double origin[3], const double size[3],
+                      const char* const lower[3], const char* const upper[3], const char* pec_shape,
+                      const char* dielectrics, double dm_frac, int strict, const int box_lo[3],
+                      const int box_hi[3], mxh_sim** out);
 int mxh_sim_destroy(mxh_sim* s);
 
 /* ---------------------------------------------------------------------------------------

@@ -98,6 +98,9 @@ MXH_SIGNATURES = {
     "mxh_sim_create_box": (C.c_int, [C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_char_p),
                                      C.POINTER(C.c_char_p), C.c_char_p, C.c_int, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.POINTER(vp)]),
+    "mxh_sim_create_ex": (C.c_int, [C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_char_p),
+                                    C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_double, C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp)]),
     "mxh_sim_dist_op": (C.c_int, [vp, C.c_char_p, C.c_double, c_i64p, c_i64p, C.POINTER(c_i64p),
                                   C.POINTER(c_i64p), C.POINTER(c_dp), C.POINTER(c_i64p), c_i64p,
                                   C.POINTER(c_i64p), c_ip]),

@@ -271,7 +271,9 @@ class Sim:
     """Grid + BCs + PEC shape -> assembled operators (MxEMSim::setup + MxEMOps + initMatrices)."""
 
     def __init__(self, n, origin=(0.0, 0.0, 0.0), size=(1.0, 1.0, 1.0), lower=("periodic",) * 3,
-                 upper=("periodic",) * 3, pec_shape=None, strict=True):
+                 upper=("periodic",) * 3, pec_shape=None, strict=True, dielectrics=None, dm_frac=0.0):
+        """dielectrics: list of (eps, shape_spec); eps = 3 diagonal numbers, or 6 (diag + the deck's
+        `eps off diag` triple), or a scalar for an isotropic material."""
         self.lib = _lib.load_mxhost()
         n = [int(n)] * 3 if np.ndim(n) == 0 else [int(v) for v in n]
         self.n = n
@@ -281,8 +283,15 @@ class Sim:
         lo = (C.c_char_p * 3)(*[s.encode() for s in lower])
         up = (C.c_char_p * 3)(*[s.encode() for s in upper])
         h = C.c_void_p()
-        _chk(self.lib.mxh_sim_create(nn, oo, ss, lo, up, pec_shape.encode() if pec_shape else None,
-                                     int(bool(strict)), C.byref(h)), self.lib, "mxh")
+        dspec = None
+        if dielectrics:
+            items = []
+            for eps, shape in dielectrics:
+                e = [float(eps)] * 3 if np.ndim(eps) == 0 else [float(v) for v in eps]
+                items.append(",".join(repr(v) for v in e) + " : " + shape)
+            dspec = " | ".join(items).encode()
+        _chk(self.lib.mxh_sim_create_ex(nn, oo, ss, lo, up, pec_shape.encode() if pec_shape else None, dspec,
+                                        float(dm_frac), int(bool(strict)), None, None, C.byref(h)), self.lib, "mxh")
         self.h = h
 
     @classmethod

@@ -42,8 +42,8 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
   }
   if (complexProblem_ && sizeof(S) == sizeof(double))
     throw std::runtime_error("phase shifts need the complex assembler");
-  B_.name = "bfield"; E_.name = "efield"; P_.name = "psifield";
-  B_.ncomp = 3; E_.ncomp = 3; P_.ncomp = 1;
+  B_.name = "bfield"; E_.name = "efield"; P_.name = "psifield"; D_.name = "dfield";
+  B_.ncomp = 3; E_.ncomp = 3; P_.ncomp = 1; D_.ncomp = 3;
   for (int c = 0; c < 3; ++c)
     for (int i = 0; i < 3; ++i) {
       B_.xi0[c][i] = (i == c);   // face centre: 0 along the normal, d/2 elsewhere
@@ -82,10 +82,21 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
     else if (whi_[i] - wlo_[i] > n_[i]) throw std::runtime_error("YeeAssembler: box + halo wraps onto itself");
   }
   Tick tick;
-  if (cfg_.pec) {
-    addShapeRep(B_);
-    addShapeRep(E_);
-    addShapeRep(P_);
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 3; ++i) { D_.xi0[c][i] = E_.xi0[c][i]; D_.lbc[c][i] = E_.lbc[c][i]; D_.ubc[c][i] = E_.ubc[c][i]; }
+  const bool diel = !cfg_.dielectrics.empty();
+  if (cfg_.pec) {                                              // src/MxEMSim.cpp:121-129
+    addShapeRep(B_, *cfg_.pec, B_.frac);
+    addShapeRep(E_, *cfg_.pec, E_.frac);
+    addShapeRep(P_, *cfg_.pec, P_.frac);
+    if (diel) addShapeRep(D_, *cfg_.pec, D_.frac);
+  }
+  for (const YeeDielectric& dl : cfg_.dielectrics) {           // src/MxEMSim.cpp:131-146 (not on B)
+    if (!dl.shape) throw std::runtime_error("YeeAssembler: dielectric '" + dl.name + "' has no shape");
+    for (YeeField* F : {&E_, &D_, &P_}) {
+      F->dielFrac.emplace_back();
+      addShapeRep(*F, *dl.shape, F->dielFrac.back());
+    }
   }
   tick("fractions");
   // "any used component keeps the whole B cell" lookup over the extended lattice
@@ -103,6 +114,9 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
   setMap(B_);
   setMap(E_);
   setMap(P_);
+  if (diel) {                                                  // dfield->setMap(efield), src/MxEMSim.cpp:196-197
+    D_.gids = E_.gids; D_.wcell = E_.wcell; D_.owned = E_.owned; D_.lidOfWin = E_.lidOfWin;
+  }
   tick("maps");
 }
 
@@ -159,12 +173,12 @@ double YeeAssembler<S>::fracAt(const YeeField& F, int comp, const int c[3]) cons
 }
 
 template <typename S>
-void YeeAssembler<S>::addShapeRep(YeeField& F) {               // src/MxGridField.cpp:193-226
-  const Shape& shape = *cfg_.pec;
+void YeeAssembler<S>::addShapeRep(const YeeField& F, const Shape& shape,
+                                  std::vector<UVec<double>>& out) const {   // src/MxGridField.cpp:193-226
   const int64_t next = extSize();
-  F.frac.assign(F.ncomp, UVec<double>());
+  out.assign(F.ncomp, UVec<double>());
   for (int comp = 0; comp < F.ncomp; ++comp) {
-    UVec<double>& fr = F.frac[comp];
+    UVec<double>& fr = out[comp];
     fr.resize(next);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int i = wlo_[0] - 1; i <= whi_[0]; ++i)
@@ -178,7 +192,7 @@ void YeeAssembler<S>::addShapeRep(YeeField& F) {               // src/MxGridFiel
           for (int a = 0; a < 3; ++a)
             p[a] = (cfg_.origin[a] + double(ic[a]) * d_[a]) + (F.xi0[comp][a] ? 0.0 : 0.5 * d_[a]);
           double f;
-          if (&F == &B_) f = rectFraction(shape, p, comp, d_[(comp + 1) % 3], d_[(comp + 2) % 3]);
+          if (&F == &B_ || &F == &D_) f = rectFraction(shape, p, comp, d_[(comp + 1) % 3], d_[(comp + 2) % 3]);
           else if (&F == &E_) f = segmentFraction(shape, p, comp, d_[comp]);
           else f = boxFraction(shape, p, d_[0], d_[1], d_[2]);
           fr[extIndex(u)] = f;
@@ -269,6 +283,7 @@ std::complex<double> YeeAssembler<S>::factor(const YeeField& F, int comp, const 
     if (cfg_.dmFrac > 0.0 && !F.frac.empty() && fracAt(F, comp, c) < cfg_.dmFrac) return 0.0;
     return res;
   }
+  if (&F == &D_) return res;                                   // no override: MxGridField::getCompFactor
   int probe[3] = {c[0], c[1], c[2]};
   if (!cfg_.strict) interior(F, comp, c, probe);
   return use(F, comp, probe) ? res : std::complex<double>(0.0);  // src/MxYeeFitEField.cpp:91-98, MxYeePsiField.cpp:117-124
@@ -455,6 +470,252 @@ Csr<S> YeeAssembler<S>::fracs(const YeeField& F, bool inverse) const {   // src/
 }
 
 template <typename S>
+double YeeAssembler<S>::dielFracAt(const YeeField& F, size_t diel, int comp, const int c[3]) const {
+  const int64_t e = extIndex(c);
+  return e < 0 ? 0.0 : F.dielFrac[diel][comp][e];
+}
+
+namespace {
+
+void matmul3(const double x[3][3], const double y[3][3], double out[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc += x[i][k] * y[k][j];
+      out[i][j] = acc;
+    }
+}
+
+void inverse3(const double a[3][3], double r[3][3]) {   // cofactors, same expression order as mx::inverse
+  const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) -
+                     a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                     a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+  r[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) / det;
+  r[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det;
+  r[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
+  r[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) / det;
+  r[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det;
+  r[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+  r[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) / det;
+  r[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det;
+  r[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+}
+
+// gamma = I + n n^T (I - eps) / (n . eps n), pi = eps gamma   (src/MxYeeFitInvEps.cpp:345-347,365-366)
+void gammaPi(const double eps[3][3], const double n[3], double gamma[3][3], double pi[3][3]) {
+  double epsn[3], ime[3][3], nn[3][3], prod[3][3];
+  for (int i = 0; i < 3; ++i) epsn[i] = eps[i][0] * n[0] + eps[i][1] * n[1] + eps[i][2] * n[2];
+  const double denom = n[0] * epsn[0] + n[1] * epsn[1] + n[2] * epsn[2];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { ime[i][j] = (i == j ? 1.0 : 0.0) - eps[i][j]; nn[i][j] = n[i] * n[j]; }
+  matmul3(nn, ime, prod);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) gamma[i][j] = (i == j ? 1.0 : 0.0) + prod[i][j] / denom;
+  matmul3(eps, gamma, pi);
+}
+
+}  // namespace
+
+// tupleUpdate, src/MxYeeFitInvEps.cpp:305-385: length-fraction weighted rows of gamma times the
+// inverse of the area-fraction weighted rows of pi, over the dielectrics and the background
+template <typename S>
+void YeeAssembler<S>::tupleUpdate(const int comps[3], const int cells[3][3], const double n[3],
+                                  double out[3][3]) const {
+  double aveG[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, aveP[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  double lsum[3] = {0, 0, 0}, asum[3] = {0, 0, 0}, gamma[3][3], pi[3][3];
+  for (size_t i = 0; i < cfg_.dielectrics.size(); ++i) {
+    double lf[3] = {0, 0, 0}, af[3] = {0, 0, 0};
+    for (int j = 0; j < 3; ++j) {
+      const int c = comps[j];
+      lf[c] = dielFracAt(E_, i, c, cells[j]);
+      af[c] = dielFracAt(D_, i, c, cells[j]);
+      lsum[c] += lf[c];
+      asum[c] += af[c];
+    }
+    gammaPi(cfg_.dielectrics[i].eps, n, gamma, pi);
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) { aveG[j][k] += lf[j] * gamma[j][k]; aveP[j][k] += af[j] * pi[j][k]; }
+  }
+  const double bg[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  gammaPi(bg, n, gamma, pi);
+  for (int j = 0; j < 3; ++j) {
+    const double lfj = 1.0 - lsum[j], afj = 1.0 - asum[j];
+    for (int k = 0; k < 3; ++k) { aveG[j][k] += lfj * gamma[j][k]; aveP[j][k] += afj * pi[j][k]; }
+  }
+  double inv[3][3];
+  inverse3(aveP, inv);
+  matmul3(aveG, inv, out);
+}
+
+// getNormal, src/MxYeeFitInvEps.cpp:254-302
+template <typename S>
+void YeeAssembler<S>::stencilNormal(int comp0, const int cell[3], const int scomps[9], const int scells[9][3],
+                                    double n[3]) const {
+  Vec3 p;
+  for (int a = 0; a < 3; ++a) p[a] = (cfg_.origin[a] + double(cell[a]) * d_[a]) + (E_.xi0[comp0][a] ? 0.0 : 0.5 * d_[a]);
+  double norms[8][3];
+  int count = 0;
+  for (size_t i = 0; i < cfg_.dielectrics.size() && count < 8; ++i) {
+    bool cut = false;
+    for (int s = 0; s < 9; ++s) {
+      const double lf = dielFracAt(E_, i, scomps[s], scells[s]), af = dielFracAt(D_, i, scomps[s], scells[s]);
+      if ((lf != 0 && lf != 1) || (af != 0 && af != 1)) cut = true;
+    }
+    if (cut) {
+      const Vec3 g = cfg_.dielectrics[i].shape->gradFunc(p);
+      const double nn = norm(g);
+      for (int k = 0; k < 3; ++k) norms[count][k] = g[k] / nn;
+      ++count;
+    }
+  }
+  if (count == 0) { n[0] = 1.0; n[1] = 0.0; n[2] = 0.0; return; }
+  double tot[3] = {0, 0, 0};
+  for (int i = 0; i < count; ++i) {
+    double sgn = 1.0;
+    if (i > 0 && (norms[0][0] * norms[i][0] + norms[0][1] * norms[i][1] + norms[0][2] * norms[i][2]) < 0) sgn = -1.0;
+    for (int k = 0; k < 3; ++k) tot[k] += sgn * norms[i][k];
+  }
+  const double nn = std::sqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2]);
+  for (int k = 0; k < 3; ++k) n[k] = tot[k] / nn;
+}
+
+// MxYeeFitInvEps::setMatrix, src/MxYeeFitInvEps.cpp:421-560 (3-D, real eps, no PML).  Entries whose
+// column is not in the map are left out (Epetra never imports a value for such a column).
+template <typename S>
+Csr<S> YeeAssembler<S>::invEps() const {
+  const int64_t nrows = (int64_t)E_.gids.size();
+  UVec<int32_t> cols(nrows * 9);
+  UVec<S> vals(nrows * 9);
+  UVec<int32_t> cnt(nrows);
+  static const int tupleInds[8][3] = {{0, 1, 5}, {0, 1, 6}, {0, 2, 5}, {0, 2, 6}, {0, 3, 7}, {0, 3, 8}, {0, 4, 7}, {0, 4, 8}};
+  const size_t nd = cfg_.dielectrics.size();
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int comp0 = (int)(E_.gids[r] % 3);
+    int ucell[3], cell[3];
+    winCell(E_.wcell[r], ucell);
+    canon(ucell, cell);
+    bool inDiel = false, epsDiag = false;
+    double epsHere = 1.0;
+    for (size_t i = 0; i < nd; ++i) {                                        // :462-479
+      const double l0 = dielFracAt(E_, i, comp0, cell), a0 = dielFracAt(D_, i, comp0, cell);
+      const double (*e)[3] = cfg_.dielectrics[i].eps;
+      if (l0 == 1 && a0 == 1) {
+        inDiel = true;
+        epsDiag = !(std::abs(e[0][1]) > 0.0 || std::abs(e[0][2]) > 0.0 || std::abs(e[1][2]) > 0.0);   // checkIsDiag, dEps = 0
+        epsHere = e[comp0][comp0];
+        break;
+      } else if (l0 == 0 && a0 == 0) {
+        continue;
+      } else {
+        inDiel = true;
+        break;
+      }
+    }
+    if (!inDiel) { epsDiag = true; epsHere = 1.0; }
+    int32_t* rc = cols.data() + r * 9;
+    S* rv = vals.data() + r * 9;
+    if (epsDiag) {                                                           // :505-512
+      const std::complex<double> fac = factor(D_, comp0, cell);
+      rc[0] = (int32_t)r;
+      rv[0] = toScalar(fac / epsHere);
+      cnt[r] = 1;
+      continue;
+    }
+    const int comp1 = (comp0 + 1) % 3, comp2 = (comp0 + 2) % 3;              // getStencil, :35-71
+    int scomps[9] = {comp0, comp1, comp1, comp1, comp1, comp2, comp2, comp2, comp2};
+    int scells[9][3];
+    for (int s = 0; s < 9; ++s) for (int a = 0; a < 3; ++a) scells[s][a] = cell[a];
+    scells[1][comp1] -= 1;
+    scells[3][comp0] += 1; scells[3][comp1] -= 1;
+    scells[4][comp0] += 1;
+    scells[5][comp2] -= 1;
+    scells[7][comp0] += 1; scells[7][comp2] -= 1;
+    scells[8][comp0] += 1;
+    double normal[3];
+    stencilNormal(comp0, cell, scomps, scells, normal);
+    int use[8], nt = 0;                                                       // getTuples, :127-175
+    for (int t = 0; t < 8; ++t) {
+      bool ok = true;
+      if (cfg_.pec)
+        for (int j = 0; j < 3; ++j) {
+          const int si = tupleInds[t][j];
+          if (fracAt(E_, scomps[si], scells[si]) == 0) ok = false;
+        }
+      if (ok) use[nt++] = t;
+    }
+    double svals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const double ntd = double(nt);
+    for (int u = 0; u < nt; ++u) {                                            // :519-531
+      const int* t = tupleInds[use[u]];
+      int tcomps[3], tcells[3][3];
+      for (int j = 0; j < 3; ++j) { tcomps[j] = scomps[t[j]]; for (int a = 0; a < 3; ++a) tcells[j][a] = scells[t[j]][a]; }
+      double m[3][3];
+      tupleUpdate(tcomps, tcells, normal, m);
+      for (int j = 0; j < 3; ++j) svals[t[j]] += m[comp0][scomps[t[j]]] / ntd;
+    }
+    int n = 0;
+    for (int s = 0; s < 9; ++s) {                                             // :533-537
+      const std::complex<double> fac = factor(D_, scomps[s], scells[s]);
+      int ic[3];
+      interior(D_, scomps[s], scells[s], ic);
+      const int32_t lid = lidOf(D_, scomps[s], ic);
+      if (lid < 0) continue;
+      rc[n] = lid;
+      rv[n] = S(svals[s]) * toScalar(fac);
+      ++n;
+    }
+    // sort by column, merge repeated columns in insertion order (Epetra FillComplete)
+    for (int x = 1; x < n; ++x) {
+      const int32_t cc = rc[x]; const S vv = rv[x];
+      int y = x - 1;
+      while (y >= 0 && rc[y] > cc) { rc[y + 1] = rc[y]; rv[y + 1] = rv[y]; --y; }
+      rc[y + 1] = cc; rv[y + 1] = vv;
+    }
+    int w = 0;
+    for (int x = 0; x < n; ++x) {
+      if (w > 0 && rc[w - 1] == rc[x]) rv[w - 1] += rv[x];
+      else { rc[w] = rc[x]; rv[w] = rv[x]; ++w; }
+    }
+    cnt[r] = w;
+  }
+  Csr<S> m;
+  m.nrows = nrows; m.ncols = nrows;
+  m.rowptr.resize(nrows + 1); m.rowptr[0] = 0;
+  for (int64_t r = 0; r < nrows; ++r) m.rowptr[r + 1] = m.rowptr[r] + cnt[r];
+  m.col.resize(m.rowptr[nrows]);
+  m.val.resize(m.rowptr[nrows]);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < nrows; ++r) {
+    std::copy(cols.begin() + r * 9, cols.begin() + r * 9 + cnt[r], m.col.begin() + m.rowptr[r]);
+    std::copy(vals.begin() + r * 9, vals.begin() + r * 9 + cnt[r], m.val.begin() + m.rowptr[r]);
+  }
+  return m;
+}
+
+// cellAveInvEpsOperator, src/MxYeeFitInvEps.cpp:700-790: volume-fraction average of 3/trace(eps)
+template <typename S>
+Csr<S> YeeAssembler<S>::invEpsVolAve() const {
+  UVec<S> d(P_.gids.size());
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < (int64_t)P_.gids.size(); ++r) {
+    int ucell[3], cell[3];
+    winCell(P_.wcell[r], ucell);
+    canon(ucell, cell);
+    double out = 0.0, sums = 0.0;
+    for (size_t i = 0; i < cfg_.dielectrics.size(); ++i) {
+      const double (*e)[3] = cfg_.dielectrics[i].eps;
+      const double fr = dielFracAt(P_, i, 0, cell);
+      sums = sums + fr;
+      out = out + fr * (3.0 / (e[0][0] + e[1][1] + e[2][2]));
+    }
+    out = out + (1.0 - sums) * (3.0 / 3.0);
+    d[r] = S(out);
+  }
+  return diagonal<S>(d);
+}
+
+template <typename S>
 std::vector<double> YeeAssembler<S>::usedMask() const {
   std::vector<double> m(B_.gids.size());
   for (int64_t r = 0; r < (int64_t)B_.gids.size(); ++r) {
@@ -488,12 +749,18 @@ std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps() const {   // src/MxMagW
     o["dmL"] = fracs(E_, false);
     o["dmVInv"] = fracs(P_, true);
   }
+  const bool diel = hasDielectric();
+  if (diel) {                                                              // src/MxEMOps.cpp:66-77
+    o["invEps"] = invEps();
+    o["invEpsVolAve"] = invEpsVolAve();
+  }
   tick("primitives");
   auto opt = [&](std::vector<std::string>& v, const char* nm) { if (pec) v.push_back(nm); };
   std::vector<std::string> names;
-  names = {"curlB"}; opt(names, "dmL"); names.push_back("curlE");
+  names = {"curlB"}; if (diel) names.push_back("invEps"); opt(names, "dmL"); names.push_back("curlE");
   o["curlCurl"] = multiplyOps(o, names);                                   // :145-153
   names.clear(); opt(names, "dmA"); names.push_back("divB"); opt(names, "dmVInv");
+  if (diel) names.push_back("invEpsVolAve");
   names.push_back("gradPsi"); opt(names, "dmA");
   o["gradDiv"] = multiplyOps(o, names);                                    // :156-179
   tick("products");

@@ -33,6 +33,14 @@ namespace mx {
 enum BcKind { BC_PERIODIC = 0, BC_PEC = 1, BC_PMC = 2 };          // user-level (MxTypes.h)
 enum CompBc { CBC_PERIODIC = 0, CBC_ZERO = 1, CBC_CONSTANT = 2 };  // per component and axis
 
+// <Dielectric> block (src/MxProblem.cpp:487-527, src/MxDielectric.cpp): real symmetric tensor only
+// (a loss tangent makes eps complex; not built)
+struct YeeDielectric {
+  std::string name;
+  std::shared_ptr<const Shape> shape;
+  double eps[3][3];
+};
+
 struct YeeConfig {
   int n[3] = {16, 16, 16};
   double origin[3] = {0, 0, 0};
@@ -46,6 +54,7 @@ struct YeeConfig {
   // upper boundary); false: test the interiorised cell
   bool strict = true;
   double dmFrac = 0.0;   // <PEC> 'D-M frac' (src/MxProblem.cpp:450): B faces below it get factor 0
+  std::vector<YeeDielectric> dielectrics;   // in deck order; background is vacuum (src/MxEMSim.cpp:32-33)
   // Distributed assembly (one GPU per MxGridDomain box, src/MxGrid.cpp:171-193): the cells this
   // rank owns, [boxLo, boxHi) per axis; boxHi[i] < 0 means the whole axis, [0, n+1).  The
   // assembler works on the box grown by `halo` cells wherever the axis is split, so the owned rows
@@ -61,6 +70,7 @@ struct YeeField {
   bool xi0[3][3];                 // cell-relative coordinate == 0 along axis i for component c
   int lbc[3][3], ubc[3][3];       // CompBc per component and axis
   std::vector<UVec<double>> frac;   // per component over the extended lattice; empty: no region
+  std::vector<std::vector<UVec<double>>> dielFrac;   // [dielectric][component]: shape reps that are not a region
   UVec<int64_t> gids;             // global ids of the (window-)map entries; ascending on the owned box
   UVec<int32_t> wcell;            // window cell index of every map entry
   UVec<uint8_t> owned;            // 1 if the entry's cell lies in the owned box
@@ -75,6 +85,8 @@ class YeeAssembler {
   const YeeField& bfield() const { return B_; }
   const YeeField& efield() const { return E_; }
   const YeeField& psifield() const { return P_; }
+  const YeeField& dfield() const { return D_; }
+  bool hasDielectric() const { return !cfg_.dielectrics.empty(); }
   bool hasPec() const { return (bool)cfg_.pec; }
   const YeeConfig& config() const { return cfg_; }
   double cellSize(int i) const { return d_[i]; }
@@ -85,6 +97,9 @@ class YeeAssembler {
   Csr<S> divB() const;
   Csr<S> gradPsi() const;
   Csr<S> fracs(const YeeField& F, bool inverse) const;
+  // FIT inverse permittivity on the E map and its cell average on the Psi map (src/MxYeeFitInvEps.cpp)
+  Csr<S> invEps() const;
+  Csr<S> invEpsVolAve() const;
 
   // name -> matrix: curlE curlB divB gradPsi [dmA dmL dmVInv] curlCurl gradDiv vecLapl scaLapl mRhs
   std::map<std::string, Csr<S>> waveOps() const;
@@ -110,7 +125,7 @@ class YeeAssembler {
   double d_[3];
   std::complex<double> phase_[3];
   bool complexProblem_;
-  YeeField B_, E_, P_;
+  YeeField B_, E_, P_, D_;   // D: E's positions and map, represented by the dual faces (src/MxYeeFitDField.cpp:42-52)
   UVec<uint8_t> bcellUsed_;  // extended lattice
 
   bool windowed_;
@@ -176,7 +191,10 @@ class YeeAssembler {
   std::complex<double> baseFactor(const YeeField& F, int comp, const int c[3]) const;
   std::complex<double> factor(const YeeField& F, int comp, const int c[3]) const;
   int64_t gid(const YeeField& F, int comp, const int c[3]) const;
-  void addShapeRep(YeeField& F);
+  void addShapeRep(const YeeField& F, const Shape& shape, std::vector<UVec<double>>& out) const;
+  double dielFracAt(const YeeField& F, size_t diel, int comp, const int c[3]) const;
+  void stencilNormal(int comp0, const int cell[3], const int scomps[9], const int scells[9][3], double n[3]) const;
+  void tupleUpdate(const int comps[3], const int cells[3][3], const double n[3], double out[3][3]) const;
   void setMap(YeeField& F);
   struct Entry { int comp; int off[3]; double val; };
   Csr<S> assemble(const YeeField& rowF, const YeeField& colF, bool skipDeadRows,

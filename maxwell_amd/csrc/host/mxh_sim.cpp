@@ -69,16 +69,56 @@ std::shared_ptr<const mx::Shape> mxh_parse_shape(const char* spec) {
   return inter;
 }
 
+// "e11,e22,e33[,o0,o1,o2] : shape-spec | ..." -> dielectrics; the off-diagonal triple follows the deck's
+// `eps off diag`: eps(1,2) = o0, eps(0,2) = o1, eps(0,1) = o2 (src/MxProblem.cpp:516-518)
+std::vector<mx::YeeDielectric> mxh_parse_dielectrics(const char* spec) {
+  std::vector<mx::YeeDielectric> out;
+  if (!spec) return out;
+  std::string s(spec);
+  size_t pos = 0;
+  while (pos <= s.size()) {
+    size_t bar = s.find('|', pos);
+    if (bar == std::string::npos) bar = s.size();
+    const std::string item = s.substr(pos, bar - pos);
+    pos = bar + 1;
+    if (item.find_first_not_of(" \t\n") == std::string::npos) continue;
+    const size_t colon = item.find(':');
+    if (colon == std::string::npos) throw std::runtime_error("dielectric '" + item + "': expected 'eps : shape'");
+    const std::vector<double> e = numbers(item.substr(0, colon));
+    if (e.size() != 3 && e.size() != 6) throw std::runtime_error("dielectric '" + item + "': 3 or 6 permittivity numbers");
+    mx::YeeDielectric d;
+    d.name = "dielectric" + std::to_string(out.size());                 // src/MxProblem.cpp:493-494
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d.eps[i][j] = 0.0;
+    for (int i = 0; i < 3; ++i) d.eps[i][i] = e[(size_t)i];
+    if (e.size() == 6) {
+      d.eps[0][1] = d.eps[1][0] = e[5];
+      d.eps[0][2] = d.eps[2][0] = e[4];
+      d.eps[1][2] = d.eps[2][1] = e[3];
+    }
+    d.shape = mxh_parse_shape(item.substr(colon + 1).c_str());
+    if (!d.shape) throw std::runtime_error("dielectric '" + item + "': empty shape");
+    out.push_back(d);
+  }
+  return out;
+}
+
 extern "C" int mxh_sim_create(const int n[3], const double origin[3], const double size[3],
                               const char* const lower[3], const char* const upper[3],
                               const char* pec_shape, int strict, mxh_sim** out) {
-  return mxh_sim_create_box(n, origin, size, lower, upper, pec_shape, strict, nullptr, nullptr, out);
+  return mxh_sim_create_ex(n, origin, size, lower, upper, pec_shape, nullptr, 0.0, strict, nullptr, nullptr, out);
 }
 
 extern "C" int mxh_sim_create_box(const int n[3], const double origin[3], const double size[3],
                                   const char* const lower[3], const char* const upper[3],
                                   const char* pec_shape, int strict, const int box_lo[3],
                                   const int box_hi[3], mxh_sim** out) {
+  return mxh_sim_create_ex(n, origin, size, lower, upper, pec_shape, nullptr, 0.0, strict, box_lo, box_hi, out);
+}
+
+extern "C" int mxh_sim_create_ex(const int n[3], const double origin[3], const double size[3],
+                                 const char* const lower[3], const char* const upper[3],
+                                 const char* pec_shape, const char* dielectrics, double dm_frac, int strict,
+                                 const int box_lo[3], const int box_hi[3], mxh_sim** out) {
   try {
     if (!n || !origin || !size || !out) throw std::runtime_error("mxh_sim_create: NULL argument");
     mx::YeeConfig cfg;
@@ -89,6 +129,8 @@ extern "C" int mxh_sim_create_box(const int n[3], const double origin[3], const 
       cfg.upper[i] = mx::parseBc(upper ? upper[i] : "periodic");
     }
     cfg.pec = mxh_parse_shape(pec_shape);
+    cfg.dielectrics = mxh_parse_dielectrics(dielectrics);
+    cfg.dmFrac = dm_frac;
     cfg.strict = strict != 0;
     if (box_lo && box_hi)
       for (int i = 0; i < 3; ++i) { cfg.boxLo[i] = box_lo[i]; cfg.boxHi[i] = box_hi[i]; }
