@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <complex>
 
 #include "MxTypes.h"
 
@@ -140,6 +141,134 @@ inline void symEig(int n, std::vector<double>& A, std::vector<double>& w, std::v
   for (int i = 0; i < n; ++i) w[i] = a(i, i);
 }
 
+// Eigen-decomposition of a small general real matrix (column-major n x n) in complex arithmetic:
+// Householder reduction to Hessenberg form, single-shift QR with Givens rotations to the complex Schur
+// form T = Q^H A Q, eigenvectors of T by back substitution, X = Q Y (columns of unit 2-norm).
+// Dense O(n^3); n is the Krylov basis size (<= a few hundred).
+inline bool genEig(int n, const std::vector<double>& A, std::vector<std::complex<double> >& w,
+                   std::vector<std::complex<double> >& X) {
+  typedef std::complex<double> C;
+  std::vector<C> H((size_t)n * n), Q((size_t)n * n, C(0.0));
+  for (size_t i = 0; i < (size_t)n * n; ++i) H[i] = C(A[i], 0.0);
+  for (int i = 0; i < n; ++i) Q[i + (size_t)n * i] = C(1.0);
+  auto h = [&](int i, int j) -> C& { return H[i + (size_t)n * j]; };
+  auto q = [&](int i, int j) -> C& { return Q[i + (size_t)n * j]; };
+  // ---- Hessenberg reduction
+  std::vector<C> v(n);
+  for (int k = 0; k + 2 < n; ++k) {
+    double xn = 0.0;
+    for (int i = k + 1; i < n; ++i) xn += std::norm(h(i, k));
+    xn = std::sqrt(xn);
+    if (xn == 0.0) continue;
+    const C x0 = h(k + 1, k);
+    const C ph = std::abs(x0) > 0.0 ? x0 / std::abs(x0) : C(1.0);
+    for (int i = k + 1; i < n; ++i) v[i] = h(i, k);
+    v[k + 1] += ph * xn;
+    double vn = 0.0;
+    for (int i = k + 1; i < n; ++i) vn += std::norm(v[i]);
+    vn = std::sqrt(vn);
+    if (vn == 0.0) continue;
+    for (int i = k + 1; i < n; ++i) v[i] /= vn;
+    for (int j = 0; j < n; ++j) {            // H <- (I - 2 v v^H) H
+      C s(0.0);
+      for (int i = k + 1; i < n; ++i) s += std::conj(v[i]) * h(i, j);
+      s *= 2.0;
+      for (int i = k + 1; i < n; ++i) h(i, j) -= v[i] * s;
+    }
+    for (int i = 0; i < n; ++i) {            // H <- H (I - 2 v v^H), Q likewise
+      C s(0.0), t(0.0);
+      for (int j = k + 1; j < n; ++j) { s += h(i, j) * v[j]; t += q(i, j) * v[j]; }
+      s *= 2.0; t *= 2.0;
+      for (int j = k + 1; j < n; ++j) { h(i, j) -= s * std::conj(v[j]); q(i, j) -= t * std::conj(v[j]); }
+    }
+    for (int i = k + 2; i < n; ++i) h(i, k) = C(0.0);
+  }
+  // ---- shifted QR on the active block [lo, hi]
+  const double eps = 2.3e-16;
+  int hi = n - 1, iter = 0, total = 0;
+  std::vector<double> cs(n);
+  std::vector<C> sn(n);
+  while (hi > 0) {
+    int lo = hi;
+    while (lo > 0) {
+      const double sc = std::abs(h(lo - 1, lo - 1)) + std::abs(h(lo, lo));
+      if (std::abs(h(lo, lo - 1)) <= eps * (sc > 0.0 ? sc : 1.0)) { h(lo, lo - 1) = C(0.0); break; }
+      --lo;
+    }
+    if (lo == hi) { --hi; iter = 0; continue; }
+    if (++total > 60 * n + 200) return false;
+    ++iter;
+    // Wilkinson shift: eigenvalue of the trailing 2x2 closer to h(hi, hi); exceptional shifts on stagnation
+    C mu;
+    if (iter % 11 == 10) {
+      mu = h(hi, hi) + C(std::abs(h(hi, hi - 1)), 0.0);
+    } else {
+      const C a = h(hi - 1, hi - 1), b = h(hi - 1, hi), c = h(hi, hi - 1), d = h(hi, hi);
+      const C tr = a + d, det = a * d - b * c;
+      const C disc = std::sqrt(tr * tr * 0.25 - det);
+      const C l1 = tr * 0.5 + disc, l2 = tr * 0.5 - disc;
+      mu = std::abs(l1 - d) < std::abs(l2 - d) ? l1 : l2;
+    }
+    for (int i = lo; i <= hi; ++i) h(i, i) -= mu;
+    for (int k = lo; k < hi; ++k) {          // R = G_{hi-1} ... G_lo (H - mu I)
+      const C a = h(k, k), b = h(k + 1, k);
+      const double r = std::sqrt(std::norm(a) + std::norm(b));
+      if (r == 0.0) { cs[k] = 1.0; sn[k] = C(0.0); continue; }
+      if (std::abs(a) == 0.0) { cs[k] = 0.0; sn[k] = std::conj(b) / std::abs(b); }
+      else { cs[k] = std::abs(a) / r; sn[k] = (a / std::abs(a)) * std::conj(b) / r; }
+      for (int j = k; j < n; ++j) {
+        const C t1 = h(k, j), t2 = h(k + 1, j);
+        h(k, j) = cs[k] * t1 + sn[k] * t2;
+        h(k + 1, j) = -std::conj(sn[k]) * t1 + cs[k] * t2;
+      }
+      h(k + 1, k) = C(0.0);
+    }
+    for (int k = lo; k < hi; ++k) {          // H = R G_lo^H ... G_{hi-1}^H, Q <- Q G^H
+      const int top = std::min(k + 1, hi);
+      for (int i = 0; i <= top; ++i) {
+        const C t1 = h(i, k), t2 = h(i, k + 1);
+        h(i, k) = cs[k] * t1 + std::conj(sn[k]) * t2;
+        h(i, k + 1) = -sn[k] * t1 + cs[k] * t2;
+      }
+      for (int i = 0; i < n; ++i) {
+        const C t1 = q(i, k), t2 = q(i, k + 1);
+        q(i, k) = cs[k] * t1 + std::conj(sn[k]) * t2;
+        q(i, k + 1) = -sn[k] * t1 + cs[k] * t2;
+      }
+    }
+    for (int i = lo; i <= hi; ++i) h(i, i) += mu;
+  }
+  // ---- eigenvectors of the triangular factor, transformed back
+  w.resize(n);
+  X.assign((size_t)n * n, C(0.0));
+  double tnorm = 0.0;
+  for (int j = 0; j < n; ++j) for (int i = 0; i <= j; ++i) tnorm = std::max(tnorm, std::abs(h(i, j)));
+  const double tiny = eps * (tnorm > 0.0 ? tnorm : 1.0);
+  std::vector<C> y(n);
+  for (int k = 0; k < n; ++k) {
+    w[k] = h(k, k);
+    for (int i = 0; i < n; ++i) y[i] = C(0.0);
+    y[k] = C(1.0);
+    for (int j = k - 1; j >= 0; --j) {
+      C s(0.0);
+      for (int i = j + 1; i <= k; ++i) s += h(j, i) * y[i];
+      C den = h(j, j) - w[k];
+      if (std::abs(den) < tiny) den = C(tiny);
+      y[j] = -s / den;
+    }
+    double nrm = 0.0;
+    for (int i = 0; i < n; ++i) {
+      C s(0.0);
+      for (int j = 0; j <= k; ++j) s += q(i, j) * y[j];
+      X[i + (size_t)n * k] = s;
+      nrm += std::norm(s);
+    }
+    nrm = std::sqrt(nrm);
+    for (int i = 0; i < n; ++i) X[i + (size_t)n * k] /= nrm;
+  }
+  return true;
+}
+
 }  // namespace detail
 
 // Thick-restart block Krylov-Schur (Hermitian).  Parameters as set by MxSolver
@@ -158,12 +287,13 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
     tol_ = pl.get("Convergence Tolerance", 1.0e-8);
     verb_ = pl.get("Verbosity", 0);
     if (!problem->isProblemSet()) throw std::invalid_argument("BlockKrylovSchurSolMgr: problem not set");
-    if (!problem->isHermitian())
-      throw std::invalid_argument("BlockKrylovSchurSolMgr: only the Hermitian (PEC / vacuum) case is implemented");
+    if (!problem->isHermitian() && ScalarTraits<Scalar>::isComplex)
+      throw std::invalid_argument("BlockKrylovSchurSolMgr: the non-Hermitian path is built for real scalars only");
   }
   int getNumIters() const { return iters_; }
 
   ReturnType solve() {
+    if (!prob_->isHermitian()) return solveGeneral();
     const int b = blockSize_, nev = prob_->getNEV();
     const int maxdim = std::max(numBlocks_ * b, nev + 2 * b);     // Krylov basis size before a restart
     const int cap = maxdim + b;                                    // projected matrix capacity
@@ -286,6 +416,206 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
     }
   }
 
+  // Non-Hermitian case (dielectrics: the FIT inverse permittivity is not symmetric, src/MxSolver.cpp:68-73
+  // leaves the problem non-Hermitian).  Block Arnoldi A V_m = V_m H_m + Q R E^T; Ritz pairs from the
+  // complex eigen-decomposition of H_m; restart on a real orthonormal basis Y of the wanted Ritz vectors'
+  // span (an invariant subspace of H_m, conjugate pairs kept together):  A (V_m Y) = (V_m Y) S + Q (R Y_last),
+  // S = Y^T H_m Y - a Krylov decomposition in Stewart's sense, continued by ordinary Arnoldi steps.
+  ReturnType solveGeneral() {
+    typedef std::complex<double> C;
+    const int b = blockSize_, nev = prob_->getNEV();
+    const int maxdim = std::max(numBlocks_ * b, nev + 2 * b + 1);
+    const int cap = maxdim + b;
+    RCP<OP> op = prob_->getOperator(), M = prob_->getM();
+    RCP<MV> init = prob_->getInitVec();
+    if (init->GetNumberVecs() < b) throw std::invalid_argument("BlockKrylovSchurSolMgr: initial block smaller than the block size");
+    std::unique_ptr<MV> V(init->Clone(cap + b)), W(init->Clone(b));
+    std::unique_ptr<MV> MW(M.is_null() ? nullptr : init->Clone(b));
+    const int ldh = cap + b;
+    std::vector<double> H((size_t)ldh * cap, 0.0);               // (k x m) block Hessenberg incl. the coupling rows
+    auto Hat = [&](int i, int j) -> double& { return H[i + (size_t)ldh * j]; };
+    Dense R(b, b);
+    {
+      std::unique_ptr<const MV> i0(init->CloneView(range(0, b)));
+      W->MvAddMv(ScalarTraits<Scalar>::one(), *i0, ScalarTraits<Scalar>::zero(), *i0);
+    }
+    if (orthonormalize(*V, 0, *W, MW.get(), M, R) < b)
+      throw std::runtime_error("BlockKrylovSchur: start block is rank deficient");
+    setCols(*V, 0, *W);
+    int k = b, restarts = 0, nconv = 0;
+    iters_ = 0;
+    while (true) {
+      bool breakdown = false;
+      while (k - b < maxdim) {
+        {
+          std::unique_ptr<const MV> Vact(V->CloneView(range(k - b, b)));
+          op->Apply(*Vact, *W);
+        }
+        ++iters_;
+        std::vector<double> scale(b);
+        for (int j = 0; j < b; ++j) {
+          std::unique_ptr<MV> wj(W->CloneViewNonConst(range(j, 1)));
+          std::unique_ptr<MV> mwj(MW ? MW->CloneViewNonConst(range(0, 1)) : nullptr);
+          scale[j] = mnorm(*wj, mwj.get(), M);
+        }
+        Dense h(k, b), h2(k, b);
+        std::unique_ptr<const MV> Vk(V->CloneView(range(0, k)));
+        innerProd(*Vk, *W, MW.get(), M, h);
+        W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h, ScalarTraits<Scalar>::one());
+        innerProd(*Vk, *W, MW.get(), M, h2);
+        W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h2, ScalarTraits<Scalar>::one());
+        for (int j = 0; j < b; ++j)
+          for (int i = 0; i < k; ++i)
+            Hat(i, k - b + j) = ScalarTraits<Scalar>::real(h(i, j)) + ScalarTraits<Scalar>::real(h2(i, j));
+        const int rank = orthonormalize(*V, k, *W, MW.get(), M, R, &scale);
+        for (int j = 0; j < b; ++j) for (int r = 0; r < b; ++r) Hat(k + r, k - b + j) = ScalarTraits<Scalar>::real(R(r, j));
+        setCols(*V, k, *W);
+        k += b;
+        if (rank < b) { breakdown = true; break; }
+      }
+      const int m = k - b;
+      std::vector<double> A((size_t)m * m);
+      for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) A[i + (size_t)m * j] = Hat(i, j);
+      std::vector<C> w, X;
+      if (!detail::genEig(m, A, w, X)) throw std::runtime_error("BlockKrylovSchur: dense QR iteration did not converge");
+      std::vector<int> order(m);
+      std::iota(order.begin(), order.end(), 0);
+      sortRitzComplex(w, order);
+      // residual of Ritz pair c: || (coupling rows of H) * x[m-b:m] ||
+      std::vector<double> resid(m);
+      for (int c = 0; c < m; ++c) {
+        const int i = order[c];
+        double r2 = 0.0;
+        for (int r = 0; r < b; ++r) {
+          C sum(0.0);
+          for (int qq = 0; qq < b; ++qq) sum += Hat(m + r, m - b + qq) * X[(m - b + qq) + (size_t)m * i];
+          r2 += std::norm(sum);
+        }
+        resid[c] = std::sqrt(r2);
+      }
+      nconv = 0;
+      while (nconv < std::min(nev, m) && resid[nconv] <= tol_ * std::abs(w[order[nconv]])) ++nconv;
+      if (verb_ > 0) {
+        std::cout << "BlockKrylovSchur (general): restart " << restarts << ", basis " << m << ", converged " << nconv << "/" << nev << "\n";
+        for (int c = 0; c < std::min(nev, m); ++c)
+          std::cout << "   theta = " << w[order[c]] << "   residual = " << resid[c] << "\n";
+      }
+      const bool done = nconv >= nev || restarts >= maxRestarts_ || breakdown;
+      int want = done ? std::min(nev, m) : std::max(nev + b, (nev + m) / 2);
+      if (!done && want > m - b - 1) want = m - b - 1;
+      if (want < 1) want = 1;
+      // ---- real basis of the wanted Ritz vectors: x for a real Ritz value, (Re x, Im x) for a conjugate pair
+      const double imtol = 1e-12;
+      std::vector<std::vector<double> > cols;     // raw real columns (length m)
+      std::vector<int> colIndex;                  // Anasazi index: 0 real, +1 / -1 real / imaginary part of a pair
+      std::vector<C> colTheta;
+      std::vector<double> colResid;
+      std::vector<char> used(m, 0);
+      for (int c = 0; c < m && (int)cols.size() < want; ++c) {
+        const int i = order[c];
+        if (used[i]) continue;
+        used[i] = 1;
+        const bool real = std::fabs(w[i].imag()) <= imtol * std::max(std::abs(w[i]), 1e-300);
+        const C* x = &X[(size_t)m * i];
+        if (real) {
+          int big = 0;
+          for (int r = 1; r < m; ++r) if (std::abs(x[r]) > std::abs(x[big])) big = r;
+          const C ph = std::conj(x[big]) / std::abs(x[big]);       // rotate to a real vector
+          std::vector<double> col(m);
+          for (int r = 0; r < m; ++r) col[r] = (x[r] * ph).real();
+          cols.push_back(col); colIndex.push_back(0); colTheta.push_back(C(w[i].real(), 0.0)); colResid.push_back(resid[c]);
+        } else {
+          // its conjugate partner is another Ritz value: mark it used so the pair enters once
+          int partner = -1;
+          double best = 1e300;
+          for (int j = 0; j < m; ++j)
+            if (!used[j]) { const double dd = std::abs(w[j] - std::conj(w[i])); if (dd < best) { best = dd; partner = j; } }
+          if (partner >= 0) used[partner] = 1;
+          std::vector<double> re(m), im(m);
+          for (int r = 0; r < m; ++r) { re[r] = x[r].real(); im[r] = x[r].imag(); }
+          const C th = w[i].imag() > 0 ? w[i] : std::conj(w[i]);
+          if (w[i].imag() < 0) for (int r = 0; r < m; ++r) im[r] = -im[r];
+          cols.push_back(re); colIndex.push_back(1); colTheta.push_back(th); colResid.push_back(resid[c]);
+          cols.push_back(im); colIndex.push_back(-1); colTheta.push_back(std::conj(th)); colResid.push_back(resid[c]);
+        }
+      }
+      const int keep = (int)cols.size();
+      if (done) {
+        Dense Zk(m, keep);
+        for (int c = 0; c < keep; ++c) for (int i = 0; i < m; ++i) Zk(i, c) = cols[c][i];
+        std::unique_ptr<MV> Yv(init->Clone(keep));
+        {
+          std::unique_ptr<const MV> Vm(V->CloneView(range(0, m)));
+          Yv->MvTimesMatAddMv(ScalarTraits<Scalar>::one(), *Vm, Zk, ScalarTraits<Scalar>::zero());
+        }
+        Eigensolution<Scalar, MV> sol;
+        sol.numVecs = keep;
+        sol.Evecs = RCP<MV>(Yv.release());
+        for (int c = 0; c < keep; ++c) {
+          Value<double> v; v.realpart = colTheta[c].real(); v.imagpart = colTheta[c].imag();
+          sol.Evals.push_back(v);
+          sol.index.push_back(colIndex[c]);
+        }
+        prob_->setSolution(sol);
+        numConverged_ = nconv;
+        residuals_ = colResid;
+        return nconv >= nev ? Converged : Unconverged;
+      }
+      // ---- orthonormalise the columns (modified Gram-Schmidt, twice) -> Y (m x keep)
+      std::vector<std::vector<double> > Y = cols;
+      for (int c = 0; c < keep; ++c) {
+        for (int pass = 0; pass < 2; ++pass)
+          for (int p = 0; p < c; ++p) {
+            double d = 0.0;
+            for (int i = 0; i < m; ++i) d += Y[p][i] * Y[c][i];
+            for (int i = 0; i < m; ++i) Y[c][i] -= d * Y[p][i];
+          }
+        double nrm = 0.0;
+        for (int i = 0; i < m; ++i) nrm += Y[c][i] * Y[c][i];
+        nrm = std::sqrt(nrm);
+        if (!(nrm > 1e-13)) throw std::runtime_error("BlockKrylovSchur: wanted Ritz vectors are linearly dependent");
+        for (int i = 0; i < m; ++i) Y[c][i] /= nrm;
+      }
+      // S = Y^T H_m Y and the new coupling rows (R E^T) Y
+      std::vector<double> HY((size_t)m * keep, 0.0), S((size_t)keep * keep, 0.0), Bt((size_t)b * keep, 0.0);
+      for (int c = 0; c < keep; ++c)
+        for (int j = 0; j < m; ++j) {
+          const double yj = Y[c][j];
+          if (yj == 0.0) continue;
+          for (int i = 0; i < m; ++i) HY[i + (size_t)m * c] += Hat(i, j) * yj;
+        }
+      for (int c = 0; c < keep; ++c)
+        for (int p = 0; p < keep; ++p) {
+          double d = 0.0;
+          for (int i = 0; i < m; ++i) d += Y[p][i] * HY[i + (size_t)m * c];
+          S[p + (size_t)keep * c] = d;
+        }
+      for (int c = 0; c < keep; ++c)
+        for (int r = 0; r < b; ++r) {
+          double d = 0.0;
+          for (int qq = 0; qq < b; ++qq) d += Hat(m + r, m - b + qq) * Y[c][m - b + qq];
+          Bt[r + (size_t)b * c] = d;
+        }
+      Dense Zk(m, keep);
+      for (int c = 0; c < keep; ++c) for (int i = 0; i < m; ++i) Zk(i, c) = Y[c][i];
+      std::unique_ptr<MV> Yv(init->Clone(keep));
+      {
+        std::unique_ptr<const MV> Vm(V->CloneView(range(0, m)));
+        Yv->MvTimesMatAddMv(ScalarTraits<Scalar>::one(), *Vm, Zk, ScalarTraits<Scalar>::zero());
+      }
+      std::unique_ptr<MV> Qb(V->CloneCopy(range(m, b)));
+      setCols(*V, 0, *Yv);
+      setCols(*V, keep, *Qb);
+      std::fill(H.begin(), H.end(), 0.0);
+      for (int c = 0; c < keep; ++c) {
+        for (int p = 0; p < keep; ++p) Hat(p, c) = S[p + (size_t)keep * c];
+        for (int r = 0; r < b; ++r) Hat(keep + r, c) = Bt[r + (size_t)b * c];
+      }
+      k = keep + b;
+      ++restarts;
+    }
+  }
+
   int getNumConverged() const { return numConverged_; }
 
  private:
@@ -368,6 +698,14 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
     else if (which_ == "SM") std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(w[a]) < std::fabs(w[b]); });
     else if (which_ == "LR") std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a] > w[b]; });
     else if (which_ == "SR") std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a] < w[b]; });
+    else throw std::invalid_argument("BlockKrylovSchurSolMgr: unknown 'Which' = " + which_);
+  }
+
+  void sortRitzComplex(const std::vector<std::complex<double> >& w, std::vector<int>& order) const {
+    if (which_ == "LM") std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::abs(w[a]) > std::abs(w[b]); });
+    else if (which_ == "SM") std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::abs(w[a]) < std::abs(w[b]); });
+    else if (which_ == "LR") std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a].real() > w[b].real(); });
+    else if (which_ == "SR") std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a].real() < w[b].real(); });
     else throw std::invalid_argument("BlockKrylovSchurSolMgr: unknown 'Which' = " + which_);
   }
 

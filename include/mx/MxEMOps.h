@@ -25,6 +25,11 @@ class MxEMOps {
     insert("divB", p, b, a.divB());
     insert("gradPsi", b, p, a.gradPsi());
     if (mSim->hasPEC()) insert("dmVInv", p, p, a.fracs(a.psifield(), true));
+    if (mSim->hasDielectric()) {                                   // src/MxEMOps.cpp:66-77
+      if (pid == 0) std::cout << "Constructing FIT inverse epsilon operator...\n";
+      insert("invEps", e, e, a.invEps());
+      insert("invEpsVolAve", p, p, a.invEpsVolAve());
+    }
   }
   RCP<MxCrsMatrix<Scalar> > getOp(std::string name) const {
     auto it = mOps.find(name);

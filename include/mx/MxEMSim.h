@@ -55,10 +55,11 @@ class MxEMSim {
     addField("bfield", mAsm->bfield(), mAsm->usedMask(), comm);
     addField("efield", mAsm->efield(), std::vector<double>(), comm);
     addField("psifield", mAsm->psifield(), std::vector<double>(), comm);
+    if (hasDielectric()) mFields["dfield"] = mFields["efield"];   // dfield->setMap(efield), src/MxEMSim.cpp:196-197
     mPList.set("has curl null", true);
   }
   bool hasPEC() const { return (bool)mCfg.pec; }
-  bool hasDielectric() const { return false; }
+  bool hasDielectric() const { return !mCfg.dielectrics.empty(); }
   bool hasMu() const { return false; }
   bool hasPML() const { return false; }
   const MxGrid<DIM>& getGrid() const { return mGrid; }

@@ -163,6 +163,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim));
     std::vector<std::string> names;
     names.push_back("curlB");
+    if (mSim->hasDielectric()) names.push_back("invEps");
     if (mSim->hasPEC()) names.push_back("dmL");
     names.push_back("curlE");
     mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true, true, "curlCurl");
@@ -171,6 +172,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
       if (mSim->hasPEC()) names.push_back("dmA");
       names.push_back("divB");
       if (mSim->hasPEC()) names.push_back("dmVInv");
+      if (mSim->hasDielectric()) names.push_back("invEpsVolAve");
       names.push_back("gradPsi");
       if (mSim->hasPEC()) names.push_back("dmA");
       mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true, true, "gradDiv");

@@ -4,10 +4,10 @@
 // reference's lookup order: body line `name = value` first, then the tag attribute, then the
 // default (src/MxUtil.cpp:266-315).
 //
-// In scope: 3-D, Grid, BoundaryConditions, PEC with Cylinder / Sphere / Slab /
-// HalfSpace / ShapeIntersection and the generic transforms, Eigensolver / LinearSolver /
-// Preconditioner.  Dielectric / Mu / PML blocks and the remaining shape tags are rejected with a
-// message instead of being ignored (a wrong answer would be silent otherwise).
+// In scope: 3-D, Grid, BoundaryConditions, PEC and lossless Dielectric blocks with
+// Cylinder / Sphere / Slab / HalfSpace / ShapeIntersection and the generic transforms, Eigensolver /
+// LinearSolver / Preconditioner.  Mu / PML blocks, loss tangents and the remaining shape tags are
+// rejected with a message instead of being ignored (a wrong answer would be silent otherwise).
 //
 // Deviation: the reference runs the solve inside the constructor and leaves solve() empty
 // (src/MxProblem.cpp:160-175,694); here the constructor parses and assembles, solve() solves.
@@ -381,9 +381,10 @@ class MxProblem {
     else if (tag == "Grid") getGrid(node);
     else if (tag == "PEC") getPEC(node);
     else if (tag == "BoundaryConditions") getBCs(node);
-    else if (tag == "Dielectric" || tag == "Mu" || tag == "PML")
-      throw std::runtime_error("MxProblem: <" + tag + "> blocks (materials) are outside the accelerated path of "
-                               "this build (vacuum + PEC only, SURVEY §8); refusing to ignore it.");
+    else if (tag == "Dielectric") getDielectric(node);
+    else if (tag == "Mu" || tag == "PML")
+      throw std::runtime_error("MxProblem: <" + tag + "> blocks are outside the accelerated path of this build "
+                               "(vacuum / PEC / lossless dielectrics, SURVEY §8); refusing to ignore it.");
     else if (pid == 0)
       std::cout << "MxProblem<" << DIM << ">::parseNode: Did not understand XML tag: '" << tag << "'. Ignoring.\n";
   }
@@ -506,6 +507,31 @@ class MxProblem {
     cfg.dmFrac = atof(MxUtil::XML::getAttr("D-M frac", node, "0.0").c_str());
     const size_t indx = getShape(node.getChild(first));
     cfg.pec = shapes[indx];
+  }
+
+  void getDielectric(XMLNode const& node) {   // src/MxProblem.cpp:487-527
+    using MxUtil::XML::getAttr;
+    int nShapes = 0, first = -1;
+    for (int i = 0; i < node.numChildren(); ++i)
+      if (isShapeTag(node.getChild(i).getTag())) { if (first < 0) first = i; ++nShapes; }
+    if (node.numChildren() > 1 || nShapes != 1)
+      throw std::runtime_error("Dielectric object should contain exactly 1 Shape object");
+    mx::YeeDielectric d;
+    d.name = getAttr("name", node, "dielectric" + std::to_string(cfg.dielectrics.size()));
+    if (pid == 0) std::cout << "Parsed dielectric object '" << d.name << "'\n";
+    d.shape = shapes[getShape(node.getChild(first))];
+    double diag[3], off[3];
+    mxdetail::strFill(getAttr("eps diag", node, "[1.0, 1.0, 1.0]"), diag, 3, 0.0);
+    mxdetail::strFill(getAttr("eps off diag", node, "[0.0, 0.0, 0.0]"), off, 3, 0.0);
+    if (atof(getAttr("loss tangent", node, "0.0").c_str()) != 0.0)
+      throw std::runtime_error("MxProblem: <Dielectric> '" + d.name + "' has a loss tangent: complex permittivity "
+                               "needs the complex solver, which this build does not provide.");
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d.eps[i][j] = 0.0;
+    for (int i = 0; i < 3; ++i) d.eps[i][i] = diag[i];
+    d.eps[0][1] = d.eps[1][0] = off[2];
+    d.eps[0][2] = d.eps[2][0] = off[1];
+    d.eps[1][2] = d.eps[2][1] = off[0];
+    cfg.dielectrics.push_back(d);
   }
 
   void getBCs(XMLNode const& node) {   // src/MxProblem.cpp:604-645

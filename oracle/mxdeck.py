@@ -122,6 +122,7 @@ class Deck:
         self.n, self.origin, self.size = [16] * 3, [0.0] * 3, [1.0] * 3
         self.lower, self.upper, self.phase = ["periodic"] * 3, ["periodic"] * 3, [0.0] * 3
         self.pec, self.dm_frac = None, 0.0
+        self.dielectrics = []
         eig = None
         for child in root:
             if child.tag == "Grid":
@@ -135,6 +136,17 @@ class Deck:
             elif child.tag == "PEC":
                 self.dm_frac = float(get_attr("D-M frac", child, "0.0"))
                 self.pec = make_shape([c for c in child if c.tag in SHAPE_TAGS][0])
+            elif child.tag == "Dielectric":                      # src/MxProblem.cpp:487-527
+                name = get_attr("name", child, "dielectric%d" % len(self.dielectrics))
+                diag = vec(get_attr("eps diag", child, "[1.0, 1.0, 1.0]"))
+                off = vec(get_attr("eps off diag", child, "[0.0, 0.0, 0.0]"))
+                if float(get_attr("loss tangent", child, "0.0")) != 0.0:
+                    raise ValueError("loss tangent: complex permittivity is not restated")
+                eps = np.diag(diag)
+                eps[0, 1] = eps[1, 0] = off[2]
+                eps[0, 2] = eps[2, 0] = off[1]
+                eps[1, 2] = eps[2, 1] = off[0]
+                self.dielectrics.append((make_shape([c for c in child if c.tag in SHAPE_TAGS][0]), eps, name))
             elif child.tag == "Eigensolver":
                 eig = child
         self._eigensolver(eig)
@@ -159,7 +171,8 @@ class Deck:
 
     def sim(self, strict=True):
         return YeeSim(self.n, origin=self.origin, size=self.size, lower=self.lower, upper=self.upper,
-                      pec=self.pec, phase_shifts=self.phase, strict=strict, dm_frac=self.dm_frac)
+                      pec=self.pec, phase_shifts=self.phase, strict=strict, dm_frac=self.dm_frac,
+                      dielectrics=self.dielectrics)
 
 
 def load(path):

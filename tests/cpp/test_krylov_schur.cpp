@@ -3,6 +3,8 @@
 // an M-inner-product problem, a degenerate pair (block size 2) and the invariant-subspace exit.
 #include <cstdio>
 #include <cstdlib>
+#include <complex>
+#include <memory>
 #include <random>
 
 #include "mx/AnasaziCompat.hpp"
@@ -139,14 +141,115 @@ int main() {
     CHECK(nv == 3);
     CHECK(std::fabs(ev[0] - 6.0) < 1e-9 && std::fabs(ev[1] - 5.0) < 1e-9 && std::fabs(ev[2] - 4.0) < 1e-9);
   }
-  {  // 5. non-Hermitian problems are refused loudly
-    RCP<DiagOp> op(new DiagOp()); op->d.assign(10, 1.0);
-    RCP<MV> init(new DenseMV(10, 1)); init->MvRandom();
-    RCP<Anasazi::BasicEigenproblem<S, MV, OP> > prob(new Anasazi::BasicEigenproblem<S, MV, OP>(RCP<OP>(op), init));
-    prob->setNEV(1); prob->setProblem();
+  {  // 5. the small general eigen-solver: residuals on a random non-symmetric matrix
+    const int n = 40;
+    std::mt19937 g(3); std::uniform_real_distribution<double> u(-1, 1);
+    std::vector<double> A(n * n);
+    for (auto& a : A) a = u(g);
+    std::vector<std::complex<double> > w, X;
+    CHECK(Anasazi::detail::genEig(n, A, w, X));
+    std::complex<double> tr(0.0);
+    for (int c = 0; c < n; ++c) {
+      tr += w[c];
+      double r = 0;
+      for (int i = 0; i < n; ++i) {
+        std::complex<double> s(0.0);
+        for (int j = 0; j < n; ++j) s += A[i + n * j] * X[j + n * c];
+        s -= w[c] * X[i + n * c];
+        r += std::norm(s);
+      }
+      CHECK(std::sqrt(r) < 1e-11);
+    }
+    double tra = 0; for (int i = 0; i < n; ++i) tra += A[i + n * i];
+    CHECK(std::abs(tr - tra) < 1e-11);
+  }
+  {  // 5b. non-Hermitian Krylov-Schur: a non-normal operator (diagonal + strictly upper part) has the
+     //     diagonal as its spectrum; block sizes 1 and 2; with and without an M inner product
+    const int n = 300;
+    struct TriOp : OP {
+      std::vector<double> d; double off;
+      void Apply(const MV& x_, MV& y_) const {
+        const DenseMV& x = dynamic_cast<const DenseMV&>(x_); DenseMV& y = dynamic_cast<DenseMV&>(y_);
+        const int nn = x.GetVecLength();
+        for (int j = 0; j < x.GetNumberVecs(); ++j)
+          for (int i = 0; i < nn; ++i) {
+            double s = d[i] * x.at(i, j);
+            if (i + 1 < nn) s += off * x.at(i + 1, j);
+            if (i + 3 < nn) s -= 0.5 * off * x.at(i + 3, j);
+            y.at(i, j) = s;
+          }
+      }
+    };
+    for (int block = 1; block <= 2; ++block)
+      for (int withM = 0; withM < 2; ++withM) {
+        RCP<TriOp> op(new TriOp()); op->off = 0.04;   // mildly non-normal: a large off-diagonal part fills the disc |z| < 0.45 with pseudo-eigenvalues
+        for (int i = 0; i < n; ++i) op->d.push_back(1.0 / (1.0 + 0.7 * i));
+        RCP<DiagOp> M(new DiagOp());
+        for (int i = 0; i < n; ++i) M->d.push_back(0.5 + (i % 5) * 0.25);
+        RCP<MV> init(new DenseMV(n, block)); init->MvRandom();
+        RCP<Anasazi::BasicEigenproblem<S, MV, OP> > prob(new Anasazi::BasicEigenproblem<S, MV, OP>(RCP<OP>(op), init));
+        prob->setNEV(4); prob->setHermitian(false);
+        if (withM) prob->setM(RCP<OP>(M));
+        CHECK(prob->setProblem());
+        Teuchos::ParameterList pl;
+        pl.set("Which", "LM"); pl.set("Block Size", block); pl.set("Num Blocks", 14); pl.set("Maximum Restarts", 300);
+        pl.set("Convergence Tolerance", 1e-10); pl.set("Verbosity", 0);
+        Anasazi::BlockKrylovSchurSolMgr<S, MV, OP> mgr(prob, pl);
+        CHECK(mgr.solve() == Anasazi::Converged);
+        const Anasazi::Eigensolution<S, MV>& sol = prob->getSolution();
+        CHECK(sol.numVecs >= 4);
+        for (int i = 0; i < 4 && i < sol.numVecs; ++i) {
+          CHECK(std::fabs(sol.Evals[i].realpart - 1.0 / (1.0 + 0.7 * i)) < 1e-8);
+          CHECK(sol.Evals[i].imagpart == 0.0 && sol.index[i] == 0);
+        }
+        // eigenvector residual of the dominant pair
+        std::unique_ptr<MV> y(sol.Evecs->Clone(sol.numVecs));
+        op->Apply(*sol.Evecs, *y);
+        const DenseMV& xv = dynamic_cast<const DenseMV&>(*sol.Evecs); const DenseMV& yv = dynamic_cast<const DenseMV&>(*y);
+        double r = 0, nx = 0;
+        for (int i = 0; i < n; ++i) { const double t = yv.at(i, 0) - sol.Evals[0].realpart * xv.at(i, 0); r += t * t; nx += xv.at(i, 0) * xv.at(i, 0); }
+        CHECK(std::sqrt(r / nx) < 1e-8);
+      }
+  }
+  {  // 5c. complex conjugate pair: 2x2 rotation-scaling blocks; the dominant pair comes back as (Re, Im)
+    const int n = 120;
+    struct RotOp : OP {
+      void Apply(const MV& x_, MV& y_) const {
+        const DenseMV& x = dynamic_cast<const DenseMV&>(x_); DenseMV& y = dynamic_cast<DenseMV&>(y_);
+        const int nn = x.GetVecLength();
+        for (int j = 0; j < x.GetNumberVecs(); ++j) {
+          y.at(0, j) = 2.0 * x.at(0, j) - 1.5 * x.at(1, j);       // eigenvalues 2 +- 1.5 i, modulus 2.5
+          y.at(1, j) = 1.5 * x.at(0, j) + 2.0 * x.at(1, j);
+          for (int i = 2; i < nn; ++i) y.at(i, j) = (2.0 / (1.0 + 0.5 * (i - 2))) * x.at(i, j) + (i + 1 < nn ? 0.1 * x.at(i + 1, j) : 0.0);
+        }
+      }
+    };
+    RCP<OP> op(new RotOp());
+    RCP<MV> init(new DenseMV(n, 1)); init->MvRandom();
+    RCP<Anasazi::BasicEigenproblem<S, MV, OP> > prob(new Anasazi::BasicEigenproblem<S, MV, OP>(op, init));
+    prob->setNEV(3); prob->setHermitian(false);
+    CHECK(prob->setProblem());
+    Teuchos::ParameterList pl;
+    pl.set("Which", "LM"); pl.set("Block Size", 1); pl.set("Num Blocks", 16); pl.set("Maximum Restarts", 300);
+    pl.set("Convergence Tolerance", 1e-10); pl.set("Verbosity", 0);
+    Anasazi::BlockKrylovSchurSolMgr<S, MV, OP> mgr(prob, pl);
+    CHECK(mgr.solve() == Anasazi::Converged);
+    const Anasazi::Eigensolution<S, MV>& sol = prob->getSolution();
+    CHECK(sol.numVecs >= 3);
+    CHECK(std::fabs(sol.Evals[0].realpart - 2.0) < 1e-8 && std::fabs(sol.Evals[0].imagpart - 1.5) < 1e-8 && sol.index[0] == 1);
+    CHECK(std::fabs(sol.Evals[1].realpart - 2.0) < 1e-8 && std::fabs(sol.Evals[1].imagpart + 1.5) < 1e-8 && sol.index[1] == -1);
+    CHECK(std::fabs(sol.Evals[2].realpart - 2.0) < 1e-8 && sol.Evals[2].imagpart == 0.0);
+  }
+  {  // 5d. complex scalars + non-Hermitian are refused loudly (not built)
+    typedef std::complex<double> Z;
+    struct NoOp : Anasazi::Operator<Z> { void Apply(const Anasazi::MultiVec<Z>&, Anasazi::MultiVec<Z>&) const {} };
+    RCP<Anasazi::Operator<Z> > op(new NoOp());
+    RCP<Anasazi::MultiVec<Z> > init;   // never dereferenced: the constructor checks come first
+    RCP<Anasazi::BasicEigenproblem<Z, Anasazi::MultiVec<Z>, Anasazi::Operator<Z> > > prob(
+        new Anasazi::BasicEigenproblem<Z, Anasazi::MultiVec<Z>, Anasazi::Operator<Z> >(op, init));
     Teuchos::ParameterList pl;
     bool threw = false;
-    try { Anasazi::BlockKrylovSchurSolMgr<S, MV, OP> mgr(prob, pl); } catch (const std::invalid_argument&) { threw = true; }
+    try { Anasazi::BlockKrylovSchurSolMgr<Z, Anasazi::MultiVec<Z>, Anasazi::Operator<Z> > mgr(prob, pl); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);
   }
   {  // 6. the small symmetric eigen-solver

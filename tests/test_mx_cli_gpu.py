@@ -120,3 +120,22 @@ def test_periodic_vacuum_deck_exact_spectrum(ctx):
     k2 = np.sort([solver.result(i)["k2"].real for i in range(5)])
     want = _vacuum_modes(deck, 5)
     assert np.abs(k2 - want).max() / want.max() < 50 * deck.params["eigensolver : tol"], (k2, want)
+
+
+def test_dielectric_sphere_deck_non_hermitian(ctx):
+    """Config 5 physics through the deck (tests/golden/dsphmsph.mx): FIT inverse permittivity makes the
+    operator non-symmetric, MxSolver leaves the problem non-Hermitian (src/MxSolver.cpp:68-73) and the
+    general Krylov-Schur path runs with GMRES + multigrid inner solves.  Checked against the oracle's dense
+    restatement of the iterated operator and against the analytic wave numbers of example/dsphmsph.py:512-561."""
+    name = os.path.join(GOLDEN, "dsphmsph.mx")
+    deck = mxdeck.load(name)
+    solver = mx.Problem(path=name).solver(ctx)
+    assert solver.solve() == 3
+    res = [solver.result(i) for i in range(3)]
+    k2 = np.sort([r["k2"].real for r in res])
+    want = _oracle_modes(deck, 3)
+    assert np.abs(k2 - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (k2, want)
+    assert all(abs(r["k2"].imag) < 1e-9 for r in res)
+    k = np.sqrt(k2)
+    assert abs(k[0] - 2.7914257502896397024) / 2.7914 < 5e-3       # TM_11, O(h^2) at resolution 12
+    assert abs(k[1] - 4.0593020005144315490) / 4.0593 < 1e-2       # TE_21

@@ -14,7 +14,7 @@ from oracle import mxdeck
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 pytestmark = pytest.mark.usefixtures("built")
-DECKS = ["pillbox.mx", "vacuum.mx", "tilted_cavity.mx"]
+DECKS = ["pillbox.mx", "vacuum.mx", "tilted_cavity.mx", "dsphmsph.mx"]
 
 
 def _text(name):
@@ -77,6 +77,9 @@ def test_body_line_wins_over_tag_attribute():
     ("<S>\n polarization = TE\n <BoundaryConditions>\n lower bcs = [pec, foo, pec]\n </BoundaryConditions>\n</S>",
      "Invalid lower boundary condition"),
     ("<S>\n polarization = TE\n <Dielectric>\n </Dielectric>\n</S>", "Dielectric"),
+    ("<S>\n polarization = TE\n <Dielectric>\n loss tangent = 0.01\n <Sphere>\n name = s\n </Sphere>\n </Dielectric>\n</S>",
+     "loss tangent"),
+    ("<S>\n polarization = TE\n <Mu>\n </Mu>\n</S>", "<Mu>"),
     ("<S>\n polarization = TE\n <PEC>\n <Torus>\n name = t\n </Torus>\n </PEC>\n</S>", "Torus"),
     ("<S>\n polarization = TE\n <Eigensolver>\n <LinearSolver>\n <Preconditioner>\n type = foo\n </Preconditioner>\n"
      " </LinearSolver>\n </Eigensolver>\n</S>", "Preconditioner type"),
