@@ -146,6 +146,12 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     } else {
       y2 = *bWork1;
     }
+    // Faces that are in the map with a zero factor (zero-BC wall faces kept by the whole-cell rule, faces
+    // below D-M frac) are decoupled rows: (L - sigma M)_rr = -sigma M_rr, an invariant subspace with the
+    // eigenvalue -1/sigma of largest modulus.  MxSolver zeroes them in the start vector (src/MxSolver.cpp:65),
+    // but an inexact inner solve (the multigrid prolongation touches them) leaks back in at the solver
+    // tolerance and the power-like iteration amplifies it; project them out after every application.
+    MxGridField<DIM>::zeroUnusedComponents(y2, mSim->getField("bfield"));
   }
 
   int numApplies() const { return mNumApplies; }
