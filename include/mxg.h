@@ -93,6 +93,13 @@ int64_t mxg_csr_apply_bytes(const mxg_csr* a, int k);
 /* tuning knob for experiments (scripts/tune_spmv.py): selects one of the SpMV kernel variants;
  * the default (row-gather kernel) is set at creation and needs no call */
 int mxg_csr_set_kernel(mxg_csr* a, int which);
+/* Opt-in re-encoding of a real matrix for mxg_csr_apply: per block of <= 256 rows the column indices
+ * become 16-bit band codes and the values 8-bit indices into the block's table of distinct values
+ * (3 bytes per entry instead of 12; blocks that do not fit keep plain CSR).  Same values, columns and
+ * summation order: results are bit-identical to the CSR kernels.  Returns the block counts and the
+ * size of the packed stream.  Used by the eigen-driver for its operators and multigrid levels; the
+ * headline SpMV measurement of bench.py stays on the plain CSR arrays. */
+int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * multivector  (replaces Epetra_MultiVector behind MxMultiVector / MxAnasaziMV,

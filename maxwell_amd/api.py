@@ -244,6 +244,12 @@ class CsrMatrix:
     def set_kernel(self, which):
         self.lib.mxg_csr_set_kernel(self.h, which)
 
+    def compress(self):
+        """Re-encode for the compressed-stream kernel; returns (blocks, fallback blocks, stream bytes)."""
+        nb, nf, sb = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(self.lib.mxg_csr_compress(self.h, C.byref(nb), C.byref(nf), C.byref(sb)), self.lib)
+        return nb.value, nf.value, sb.value
+
     def solve(self, b, x, method="cg", tol=1e-6, restart=40, max_iters=0, precond="none", mg=None):
         opts = _lib.SolveOpts(tol, restart, max_iters, {"none": 0, "jacobi": 1, "mg": 3}[precond], 0, 0.0, 0.0,
                               mg.handle if mg is not None else None)

@@ -574,6 +574,121 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Compressed-stream variant of the row-gather kernel (opt-in: mxg_csr_compress).
+// The operators of the Yee lattice are structured: inside a block of 256 consecutive rows the
+// column indices fall into a handful of narrow bands (one per stencil leg) and, away from cut
+// cells, only a few distinct values occur.  Setup therefore re-encodes every row block as
+//   segbase[16] int32          band origins,
+//   vtab[nval <= 256] double   the block's distinct values (exact bit patterns),
+//   code[nnz] uint16           4-bit band id | 12-bit offset  ->  col = segbase[id] + offset,
+//   vid[nnz] uint8             index into vtab,
+// 3 bytes per entry instead of 12.  Blocks that do not fit (more than 16 bands or 256 distinct
+// values: cut-cell blocks) keep the plain CSR arrays and are walked row by row.  Values, columns
+// and the summation order are exactly those of the CSR arrays: results stay bit-identical.
+// ------------------------------------------------------------------------------------------
+struct CsDesc {
+  long long base;   // rowptr[r0]
+  long long soff;   // byte offset of the block's packed stream (16-byte aligned); -1: plain CSR block
+  int r0, nr, nnzb, nval;
+};
+static_assert(sizeof(CsDesc) == 32, "descriptor layout");
+constexpr int CS_SEGS = 16, CS_OFFBITS = 12, CS_MAXVAL = 256;
+
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+template <typename CFG, int CH, bool DOT>
+__global__ __launch_bounds__(CFG::SBLK) void k_spmv_cs(
+    const CsDesc* __restrict__ desc, long long nblocks, const unsigned char* __restrict__ stream,
+    const unsigned short* __restrict__ roff, const long long* __restrict__ rowptr,
+    const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y,
+    const double* __restrict__ xdot, double* __restrict__ partial) {
+  constexpr int SB = CFG::SBLK;
+  __shared__ __attribute__((aligned(16))) unsigned short scode[CFG::NNZ_BLK];
+  __shared__ __attribute__((aligned(16))) unsigned char svid[CFG::NNZ_BLK];
+  __shared__ double svtab[CS_MAXVAL];
+  __shared__ int sseg[CS_SEGS];
+  __shared__ double sred[SB / 64];
+  const long long b = xcd_block(blockIdx.x, nblocks);
+  if (b >= nblocks) return;
+  const CsDesc d = desc[b];
+  const int t = threadIdx.x;
+  if (d.nnzb > CFG::NNZ_CAP) {     // one over-long row: whole workgroup, fixed-order combine (as k_spmv_rowgather)
+    for (int j = 0; j < X.k; ++j) {
+      const double* x = X.col(j);
+      double sr = 0.0;
+      for (long long q = d.base + t; q < d.base + d.nnzb; q += SB) sr += vals[q] * x[colidx[q]];
+      if (j > 0) __syncthreads();
+      svtab[t] = sr;
+      __syncthreads();
+      if (t == 0) {
+        double tr = 0.0;
+        for (int q = 0; q < SB; ++q) tr += svtab[q];
+        Y.col(j)[d.r0] = tr;
+        if (DOT && j == 0) partial[b] = tr * xdot[d.r0];
+      }
+    }
+    return;
+  }
+  const bool packed = d.soff >= 0;
+  int o0 = 0, o1 = 0;
+  if (packed) {
+    const unsigned char* sp = stream + d.soff;
+    if (t < CS_SEGS) sseg[t] = nt_load(reinterpret_cast<const int*>(sp) + t);
+    const double* vt = reinterpret_cast<const double*>(sp + CS_SEGS * 4);
+    if (t < d.nval) svtab[t] = nt_load(vt + t);
+    const int nvpad = (d.nval + 1) & ~1;
+    const uint4v* cp = reinterpret_cast<const uint4v*>(sp + CS_SEGS * 4 + nvpad * 8);
+    const int ncode16 = (d.nnzb + 7) >> 3;            // 16-byte pieces of the code array (8 codes each)
+    if (t < ncode16) reinterpret_cast<uint4v*>(scode)[t] = nt_load(cp + t);
+    const uint4v* ip = cp + ncode16;
+    const int nid16 = (d.nnzb + 15) >> 4;
+    if (t < nid16) reinterpret_cast<uint4v*>(svid)[t] = nt_load(ip + t);
+  }
+  if (t < d.nr) {
+    const unsigned short* ro = roff + d.r0 + b + t;
+    o0 = ro[0];
+    o1 = ro[1];
+  }
+  __syncthreads();
+  for (int j = 0; j < X.k; ++j) {
+    const double* __restrict__ x = X.col(j);
+    double sum = 0.0;
+    if (packed) {
+      for (int q0 = o0; q0 < o1; q0 += CH) {
+        double v[CH], xv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const bool on = q0 + i < o1;
+          const unsigned code = on ? scode[q0 + i] : 0u;
+          const int cc = on ? sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u)) : 0;
+          v[i] = on ? svtab[svid[q0 + i]] : 0.0;
+          xv[i] = on ? x[cc] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if (q0 + i < o1) sum += v[i] * xv[i];
+      }
+    } else if (t < d.nr) {
+      for (long long q = d.base + o0; q < d.base + o1; ++q) sum += vals[q] * x[colidx[q]];
+    }
+    if (t < d.nr) __builtin_nontemporal_store(sum, Y.col(j) + d.r0 + t);
+    if (DOT && j == 0) {
+      double part = t < d.nr ? sum * xdot[d.r0 + t] : 0.0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+      if ((t & 63) == 0) sred[t >> 6] = part;
+      __syncthreads();
+      if (t == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < SB / 64; ++w) tot += sred[w];
+        partial[b] = tot;
+      }
+    }
+  }
+}
+
 // out[0] = sum of partial[0..n) in index order (single workgroup, fixed tree: reproducible)
 __global__ void k_sum_partials(const double* __restrict__ partial, long long n, double* __restrict__ out) {
   __shared__ double lds[1024];
@@ -754,6 +869,8 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
   if (a->d_dotpartial) hipFree(a->d_dotpartial);
   if (a->d_roff) hipFree(a->d_roff);
+  if (a->d_csdesc) hipFree(a->d_csdesc);
+  if (a->d_csstream) hipFree(a->d_csstream);
   if (a->d_xwdesc) hipFree(a->d_xwdesc);
   if (a->d_lcol) hipFree(a->d_lcol);
   if (a->d_send_idx) hipFree(a->d_send_idx);
@@ -935,6 +1052,121 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
   return 0;
 }
 
+
+// Packed streams for k_spmv_cs over the row blocks of the row-gather geometry (RgCfgA).
+static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const double* va) {
+  mxg_ctx* c = a->ctx;
+  std::vector<int32_t> blk = build_row_blocks(rp, a->nrows, RgCfgA::NNZ_CAP, RgCfgA::ROWS_CAP);
+  const size_t nb = blk.size() - 1;
+  std::vector<CsDesc> desc(nb);
+  std::vector<std::vector<unsigned char> > packs(nb);
+  auto work = [&](size_t b0, size_t b1) {
+    std::vector<int32_t> u;
+    std::vector<uint64_t> w;
+    for (size_t b = b0; b < b1; ++b) {
+      CsDesc d{};
+      d.r0 = blk[b]; d.nr = blk[b + 1] - blk[b];
+      d.base = rp[blk[b]];
+      d.nnzb = (int)(rp[blk[b + 1]] - d.base);
+      d.soff = -1; d.nval = 0;
+      desc[b] = d;
+      if (d.nnzb > RgCfgA::NNZ_CAP || d.nnzb == 0) continue;
+      // column bands: greedy cover of the sorted distinct columns with windows of 2^12
+      u.assign(ci + d.base, ci + d.base + d.nnzb);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      int32_t seg[CS_SEGS];
+      int nseg = 0;
+      bool ok = true;
+      for (size_t i = 0; i < u.size();) {
+        if (nseg == CS_SEGS) { ok = false; break; }
+        seg[nseg++] = u[i];
+        const int64_t lim = (int64_t)u[i] + (1 << CS_OFFBITS);
+        while (i < u.size() && u[i] < lim) ++i;
+      }
+      if (!ok) continue;
+      // distinct values by bit pattern
+      w.resize((size_t)d.nnzb);
+      std::memcpy(w.data(), va + d.base, sizeof(double) * (size_t)d.nnzb);
+      std::sort(w.begin(), w.end());
+      w.erase(std::unique(w.begin(), w.end()), w.end());
+      if (w.size() > (size_t)CS_MAXVAL) continue;
+      const int nval = (int)w.size(), nvpad = (nval + 1) & ~1;
+      const size_t ncode16 = ((size_t)d.nnzb + 7) >> 3, nid16 = ((size_t)d.nnzb + 15) >> 4;
+      std::vector<unsigned char>& pk = packs[b];
+      pk.assign(CS_SEGS * 4 + (size_t)nvpad * 8 + ncode16 * 16 + nid16 * 16, 0);
+      int32_t segpad[CS_SEGS];
+      for (int i = 0; i < CS_SEGS; ++i) segpad[i] = i < nseg ? seg[i] : 0;
+      std::memcpy(pk.data(), segpad, sizeof segpad);
+      std::memcpy(pk.data() + CS_SEGS * 4, w.data(), sizeof(uint64_t) * (size_t)nval);
+      unsigned short* code = reinterpret_cast<unsigned short*>(pk.data() + CS_SEGS * 4 + (size_t)nvpad * 8);
+      unsigned char* vid = pk.data() + CS_SEGS * 4 + (size_t)nvpad * 8 + ncode16 * 16;
+      for (int q = 0; q < d.nnzb; ++q) {
+        const int32_t col = ci[d.base + q];
+        const int sidx = (int)(std::upper_bound(seg, seg + nseg, col) - seg) - 1;
+        code[q] = (unsigned short)((sidx << CS_OFFBITS) | (col - seg[sidx]));
+        uint64_t bits;
+        std::memcpy(&bits, va + d.base + q, sizeof bits);
+        vid[q] = (unsigned char)(std::lower_bound(w.begin(), w.end(), bits) - w.begin());
+      }
+      desc[b].nval = nval;
+      desc[b].soff = 0;   // final offset assigned below
+    }
+  };
+  unsigned nthreads = std::thread::hardware_concurrency();
+  if (const char* e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) nthreads = (unsigned)v; }
+  if (nthreads > 32) nthreads = 32;
+  if (nthreads < 1 || nb < 64) nthreads = 1;
+  std::vector<std::thread> pool;
+  for (unsigned i = 0; i < nthreads; ++i)
+    pool.emplace_back(work, nb * i / nthreads, nb * (i + 1) / nthreads);
+  for (auto& th : pool) th.join();
+  size_t total = 0, nfall = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    if (desc[b].soff < 0) { if (desc[b].nnzb > 0) ++nfall; continue; }
+    desc[b].soff = (long long)total;
+    total += packs[b].size();
+  }
+  std::vector<unsigned char> stream(total + 16, 0);
+  for (size_t b = 0; b < nb; ++b)
+    if (desc[b].soff >= 0) std::memcpy(stream.data() + desc[b].soff, packs[b].data(), packs[b].size());
+  if (a->d_csdesc) hipFree(a->d_csdesc);
+  if (a->d_csstream) hipFree(a->d_csstream);
+  MXG_HIP(hipMalloc(&a->d_csdesc, sizeof(CsDesc) * std::max<size_t>(nb, 1)));
+  MXG_HIP(hipMalloc(&a->d_csstream, stream.size()));
+  if (nb) MXG_HIP(hipMemcpyAsync(a->d_csdesc, desc.data(), sizeof(CsDesc) * nb, hipMemcpyHostToDevice, c->stream));
+  MXG_HIP(hipMemcpyAsync(a->d_csstream, stream.data(), stream.size(), hipMemcpyHostToDevice, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  a->ncs = (int64_t)nb;
+  a->cs_fallback = (int64_t)nfall;
+  a->cs_bytes = (int64_t)total;
+  return 0;
+}
+
+extern "C" int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes) {
+  MXG_CHECK(a, "mxg_csr_compress: NULL argument");
+  MXG_CHECK(!a->is_complex, "mxg_csr_compress: real matrices only");
+  mxg_ctx* c = a->ctx;
+  if (a->pipe_geo != 10) MXG_TRY(build_pipe_desc(a, 10, nullptr));     // 16-bit row offsets of the same blocks
+  if (a->ncs == 0 && a->nrows > 0) {
+    std::vector<int64_t> rp((size_t)a->nrows + 1);
+    std::vector<int32_t> ci((size_t)a->nnz + 1);
+    std::vector<double> va((size_t)a->nnz + 1);
+    MXG_HIP(hipMemcpyAsync(rp.data(), a->d_rowptr, sizeof(int64_t) * (a->nrows + 1), hipMemcpyDeviceToHost, c->stream));
+    if (a->nnz > 0) {
+      MXG_HIP(hipMemcpyAsync(ci.data(), a->d_colidx, sizeof(int32_t) * a->nnz, hipMemcpyDeviceToHost, c->stream));
+      MXG_HIP(hipMemcpyAsync(va.data(), a->d_vals, sizeof(double) * a->nnz, hipMemcpyDeviceToHost, c->stream));
+    }
+    MXG_HIP(hipStreamSynchronize(c->stream));
+    MXG_TRY(build_cs(a, rp.data(), ci.data(), va.data()));
+  }
+  a->kernel = (a->kernel & ~0x1000000) | 0x750000 | 0x1000000;
+  if (nblocks) *nblocks = a->ncs;
+  if (nfallback) *nfallback = a->cs_fallback;
+  if (stream_bytes) *stream_bytes = a->cs_bytes;
+  return 0;
+}
+
 extern "C" int mxg_csr_set_kernel(mxg_csr* a, int which) {
   const int old_geo = (a->kernel >> 4) & 3, geo = (which >> 4) & 3;
   a->kernel = which;
@@ -1050,7 +1282,14 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
   }
   if (a->nrows == 0) return 0;
   (void)hipGetLastError();   // do not attribute a stale sticky error to this launch
-  if ((a->kernel & 0x30000) && !a->is_complex && a->npipe > 0) {
+  if ((a->kernel & 0x1000000) && !a->is_complex && a->ncs > 0 && a->pipe_geo == 10) {
+    const long long per = (a->ncs + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+    const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
+    hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,
+                       (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
+                       (const unsigned short*)a->d_roff, (const long long*)a->d_rowptr, a->d_colidx, a->d_vals,
+                       X, Y, (const double*)nullptr, (double*)nullptr);
+  } else if ((a->kernel & 0x30000) && !a->is_complex && a->npipe > 0) {
     const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
     const int ch = (a->kernel >> 20) & 0xF;   // gather chunk: 0 -> 8
@@ -1134,6 +1373,12 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
   const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
   const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
   (void)hipGetLastError();
+  if ((a->kernel & 0x1000000) && a->ncs == a->npipe)
+    hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,
+                       (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
+                       (const unsigned short*)a->d_roff, (const long long*)a->d_rowptr, a->d_colidx, a->d_vals,
+                       X, Y, (const double*)x->colptr(0), a->d_dotpartial);
+  else
   hipLaunchKernelGGL((k_spmv_rowgather<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,
                      (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr,
                      a->d_colidx, a->d_vals, X, Y, (const double*)x->colptr(0), a->d_dotpartial,

@@ -127,6 +127,10 @@ struct mxg_csr {
   int pipe_geo = -1;
   double* d_dotpartial = nullptr;   // per-block partials of the fused SpMV + dot
   unsigned short* d_roff = nullptr; // row-gather kernel: 16-bit in-block row offsets (nrows + nblocks + 1)
+  // compressed-stream kernel (mxg_csr_compress): 32-byte block descriptors + packed per-block streams
+  void* d_csdesc = nullptr;
+  unsigned char* d_csstream = nullptr;
+  int64_t ncs = 0, cs_fallback = 0, cs_bytes = 0;
   // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
   void* d_xwdesc = nullptr;
   unsigned short* d_lcol = nullptr;

@@ -254,3 +254,66 @@ def test_config3_cylinder_and_config5_sphere_geometries(ctx, rng):
             X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, host.shape[0], 8)
             A.apply(X, Y)
             assert np.array_equal(Y.to_numpy(), cref.spmv(host, x))
+
+
+def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng):
+    """mxg_csr_compress: 16-bit band codes + 8-bit value-table indices per row block; every operator of
+    the pillbox (bulk blocks pack, cut-cell blocks fall back to plain CSR rows), SpMV and SpMM, and the
+    fused SpMV+dot of CG give the same bits as the serial row loop."""
+    _, o = oracle_pillbox16
+    packed_any = False
+    for name in ("vecLapl", "scaLapl", "curlCurl", "curlE", "divB", "gradPsi", "mRhs"):
+        m = o[name].tocsr()
+        A = mx.CsrMatrix.from_scipy(ctx, m)
+        nb, nf, nbytes = A.compress()
+        assert nb > 0 and 0 <= nf <= nb
+        packed_any = packed_any or nf < nb
+        for k in (1, 3):
+            x = rng.uniform(-1, 1, (m.shape[1], k))
+            X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, m.shape[0], k)
+            A.apply(X, Y)
+            got = Y.to_numpy()
+            for j in range(k):
+                assert np.array_equal(got[:, j], cref.spmv(m, x[:, j])), (name, k, j)
+    assert packed_any
+    # the solver path: CG with the fused SpMV+dot on a compressed matrix reaches the same solution
+    m = yee.shifted(o["vecLapl"], o["mRhs"], -3.0).tocsr()
+    b = rng.uniform(-1, 1, m.shape[0]) * (o["mRhs"].diagonal() > 0)
+    sols = []
+    for comp in (False, True):
+        A = mx.CsrMatrix.from_scipy(ctx, m)
+        if comp:
+            A.compress()
+        B = mx.MultiVec.from_numpy(ctx, b); X = mx.MultiVec(ctx, m.shape[0], 1); X.fill(0.0)
+        it, conv, res = A.solve(B, X, method="cg", tol=1e-9, max_iters=5000, precond="jacobi")
+        assert conv
+        sols.append((it, X.to_numpy()[:, 0]))
+    assert sols[0][0] == sols[1][0] and np.array_equal(sols[0][1], sols[1][1])
+
+
+def test_compressed_stream_fallbacks(ctx, rng):
+    """Blocks with more than 16 column bands or 256 distinct values, empty rows and an over-long row."""
+    n = 9000
+    rows = [rng.choice(n, size=int(c), replace=False) for c in rng.integers(0, 12, size=n)]   # scattered columns
+    rows[5] = np.arange(n)[:2600]                        # longer than a block
+    for r in range(700, 1500):
+        rows[r] = np.array([], dtype=int)
+    for r in range(3000, 6000):                          # banded part with few distinct values: packs
+        rows[r] = np.array([c for c in (r - 600, r - 1, r, r + 1, r + 600) if 0 <= c < n])
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    indices = np.concatenate([np.sort(r) for r in rows])
+    vals = rng.uniform(-1, 1, len(indices))
+    lo, hi = indptr[3000], indptr[6000]
+    vals[lo:hi] = rng.choice([-1.0, 4.0, 0.25], size=hi - lo)
+    m = sp.csr_matrix((vals, indices, indptr), shape=(n, n))
+    x = rng.uniform(-1, 1, n)
+    want = cref.spmv(m, x)
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    nb, nf, nbytes = A.compress()
+    assert 0 < nf < nb                                    # both kinds of blocks are present
+    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, n, 1)
+    A.apply(X, Y)
+    got = Y.to_numpy()[:, 0]
+    mask = np.ones(n, bool); mask[5] = False
+    assert np.array_equal(got[mask], want[mask])
+    assert abs(got[5] - want[5]) <= 1e-12 * np.abs(m[5].data).sum()
