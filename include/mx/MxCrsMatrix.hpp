@@ -4,6 +4,7 @@
 #ifndef MX_CRS_MATRIX
 #define MX_CRS_MATRIX
 
+#include <cstdlib>
 #include <fstream>
 
 #include "MxVector.hpp"
@@ -181,6 +182,13 @@ class MxCrsMatrix {
     MX_ABI(mxg_csr_create(mRowMap->getComm()->getCtx(), mHost.nrows, mHost.ncols, 0, mHost.rowptr.data(),
                           mHost.col.data(), reinterpret_cast<const double*>(mHost.val.data()),
                           ScalarTraits<Scalar>::isComplex, NULL, &mDev), "MxCrsMatrix::fillComplete");
+    // structured operators stream 3 bytes per entry instead of 12 (mxg_csr_compress; bit-identical results);
+    // MXG_COMPRESS=0 keeps the plain CSR kernels
+    static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
+    if (compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 4096)
+      MX_ABI(mxg_csr_compress_from(mDev, mHost.rowptr.data(), mHost.col.data(),
+                                   reinterpret_cast<const double*>(mHost.val.data()), NULL, NULL, NULL),
+             "MxCrsMatrix::fillComplete (compress)");
   }
   bool mFilled;
   RCP<MxMap> mRowMap, mColMap;

@@ -100,6 +100,9 @@ int mxg_csr_set_kernel(mxg_csr* a, int which);
  * size of the packed stream.  Used by the eigen-driver for its operators and multigrid levels; the
  * headline SpMV measurement of bench.py stays on the plain CSR arrays. */
 int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes);
+/* same, encoding from the caller's host copy of the CSR arrays given to mxg_csr_create (saves reading them back) */
+int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals,
+                          int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * multivector  (replaces Epetra_MultiVector behind MxMultiVector / MxAnasaziMV,

@@ -57,6 +57,7 @@ MXG_SIGNATURES = {
     "mxg_csr_apply": (C.c_int, [vp, vp, vp, vp]),
     "mxg_csr_apply_bytes": (C.c_int64, [vp, C.c_int]),
     "mxg_csr_compress": (C.c_int, [vp, c_i64p, c_i64p, c_i64p]),
+    "mxg_csr_compress_from": (C.c_int, [vp, vp, vp, vp, c_i64p, c_i64p, c_i64p]),
     "mxg_csr_set_kernel": (C.c_int, [vp, C.c_int]),
     "mxg_mv_create": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.POINTER(vp)]),
     "mxg_mv_view": (C.c_int, [vp, c_ip, C.c_int, C.POINTER(vp)]),

@@ -1143,28 +1143,38 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
   return 0;
 }
 
-extern "C" int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes) {
+extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals,
+                                     int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes) {
   MXG_CHECK(a, "mxg_csr_compress: NULL argument");
   MXG_CHECK(!a->is_complex, "mxg_csr_compress: real matrices only");
   mxg_ctx* c = a->ctx;
-  if (a->pipe_geo != 10) MXG_TRY(build_pipe_desc(a, 10, nullptr));     // 16-bit row offsets of the same blocks
+  MXG_HIP(hipSetDevice(c->device));
+  if (a->pipe_geo != 10) MXG_TRY(build_pipe_desc(a, 10, rowptr));     // 16-bit row offsets of the same blocks
   if (a->ncs == 0 && a->nrows > 0) {
-    std::vector<int64_t> rp((size_t)a->nrows + 1);
-    std::vector<int32_t> ci((size_t)a->nnz + 1);
-    std::vector<double> va((size_t)a->nnz + 1);
-    MXG_HIP(hipMemcpyAsync(rp.data(), a->d_rowptr, sizeof(int64_t) * (a->nrows + 1), hipMemcpyDeviceToHost, c->stream));
-    if (a->nnz > 0) {
-      MXG_HIP(hipMemcpyAsync(ci.data(), a->d_colidx, sizeof(int32_t) * a->nnz, hipMemcpyDeviceToHost, c->stream));
-      MXG_HIP(hipMemcpyAsync(va.data(), a->d_vals, sizeof(double) * a->nnz, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int64_t> rp;
+    std::vector<int32_t> ci;
+    std::vector<double> va;
+    if (!rowptr || !colidx || !vals) {       // no host copy offered: read the arrays back
+      rp.resize((size_t)a->nrows + 1); ci.resize((size_t)a->nnz + 1); va.resize((size_t)a->nnz + 1);
+      MXG_HIP(hipMemcpyAsync(rp.data(), a->d_rowptr, sizeof(int64_t) * (a->nrows + 1), hipMemcpyDeviceToHost, c->stream));
+      if (a->nnz > 0) {
+        MXG_HIP(hipMemcpyAsync(ci.data(), a->d_colidx, sizeof(int32_t) * a->nnz, hipMemcpyDeviceToHost, c->stream));
+        MXG_HIP(hipMemcpyAsync(va.data(), a->d_vals, sizeof(double) * a->nnz, hipMemcpyDeviceToHost, c->stream));
+      }
+      MXG_HIP(hipStreamSynchronize(c->stream));
+      rowptr = rp.data(); colidx = ci.data(); vals = va.data();
     }
-    MXG_HIP(hipStreamSynchronize(c->stream));
-    MXG_TRY(build_cs(a, rp.data(), ci.data(), va.data()));
+    MXG_TRY(build_cs(a, rowptr, colidx, vals));
   }
-  a->kernel = (a->kernel & ~0x1000000) | 0x750000 | 0x1000000;
+  a->kernel = MXG_KERNEL_DEFAULT | 0x1000000;
   if (nblocks) *nblocks = a->ncs;
   if (nfallback) *nfallback = a->cs_fallback;
   if (stream_bytes) *stream_bytes = a->cs_bytes;
   return 0;
+}
+
+extern "C" int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes) {
+  return mxg_csr_compress_from(a, nullptr, nullptr, nullptr, nblocks, nfallback, stream_bytes);
 }
 
 extern "C" int mxg_csr_set_kernel(mxg_csr* a, int which) {
