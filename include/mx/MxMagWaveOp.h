@@ -216,6 +216,14 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   }
 
   void setLinearSolvers() {   // :286-355
+    // device copies (upload + stream encoding) belong to setup, not to the first Apply
+    mShiftedVecLapl->getRawMatrix();
+    mRhs->getRawMatrix();
+    if (mHasCurlNull) {
+      mScaLapl->getRawMatrix();
+      mEMOps->getOp("divB")->getRawMatrix();
+      mEMOps->getOp("gradPsi")->getRawMatrix();
+    }
     std::string precType = mPList.get("linear solver : prec type", "none");
     if (precType == "gmg") {
       if (pid == 0) std::cout << "Using GMRES with geometric multigrid preconditioner.\nNot implemented.\n";

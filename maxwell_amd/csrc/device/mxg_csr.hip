@@ -598,12 +598,28 @@ constexpr int CS_SEGS = 16, CS_OFFBITS = 12, CS_MAXVAL = 256;
 
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
-template <typename CFG, int CH, bool DOT>
+// EPI: 0  y = A x
+//      1  y = x + omega (rhs - A x) / diag   (one damped-Jacobi sweep; rows with diag == 0 keep x)
+//      2  y = rhs - A x                      (residual)
+// (multigrid smoother / residual fused into the product: no separate pass over the vectors)
+template <int EPI>
+__device__ inline double cs_epilogue(double ax, long long row, const double* __restrict__ x,
+                                     const double* __restrict__ rhs, const double* __restrict__ diag, double omega) {
+  if (EPI == 1) {
+    const double dg = diag[row], xr = x[row];
+    return dg != 0.0 ? xr + omega * (rhs[row] - ax) / dg : xr;
+  }
+  if (EPI == 2) return rhs[row] - ax;
+  return ax;
+}
+
+template <typename CFG, int CH, bool DOT, int EPI = 0>
 __global__ __launch_bounds__(CFG::SBLK) void k_spmv_cs(
     const CsDesc* __restrict__ desc, long long nblocks, const unsigned char* __restrict__ stream,
     const unsigned short* __restrict__ roff, const long long* __restrict__ rowptr,
     const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y,
-    const double* __restrict__ xdot, double* __restrict__ partial) {
+    const double* __restrict__ xdot, double* __restrict__ partial,
+    const double* __restrict__ rhs = nullptr, const double* __restrict__ diag = nullptr, double omega = 0.0) {
   constexpr int SB = CFG::SBLK;
   __shared__ __attribute__((aligned(16))) unsigned short scode[CFG::NNZ_BLK];
   __shared__ __attribute__((aligned(16))) unsigned char svid[CFG::NNZ_BLK];
@@ -625,7 +641,7 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_cs(
       if (t == 0) {
         double tr = 0.0;
         for (int q = 0; q < SB; ++q) tr += svtab[q];
-        Y.col(j)[d.r0] = tr;
+        Y.col(j)[d.r0] = cs_epilogue<EPI>(tr, d.r0, x, rhs, diag, omega);
         if (DOT && j == 0) partial[b] = tr * xdot[d.r0];
       }
     }
@@ -673,7 +689,7 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_cs(
     } else if (t < d.nr) {
       for (long long q = d.base + o0; q < d.base + o1; ++q) sum += vals[q] * x[colidx[q]];
     }
-    if (t < d.nr) __builtin_nontemporal_store(sum, Y.col(j) + d.r0 + t);
+    if (t < d.nr) __builtin_nontemporal_store(cs_epilogue<EPI>(sum, d.r0 + t, x, rhs, diag, omega), Y.col(j) + d.r0 + t);
     if (DOT && j == 0) {
       double part = t < d.nr ? sum * xdot[d.r0 + t] : 0.0;
 #pragma unroll
@@ -1367,6 +1383,28 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
 #undef MXG_LAUNCH
   }
   MXG_HIP(hipGetLastError());
+  return 0;
+}
+
+// Product with a fused epilogue on a compressed matrix (single column, no halo): see cs_epilogue.
+// Returns 1 without touching y when the matrix is not compressed (the caller takes the unfused path).
+int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
+                          const double* diag, double omega) {
+  if (!((a->kernel & 0x1000000) && !a->is_complex && a->ncs > 0 && a->pipe_geo == 10 && a->nghost == 0 &&
+        a->nneigh == 0 && x->k == 1 && y->k == 1 && x->base != y->base))
+    return 1;
+  const MvDesc X = x->desc(), Y = y->desc();
+  const long long per = (a->ncs + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+  const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
+  (void)hipGetLastError();
+#define MXG_CS_EPI(E)                                                                                          \
+  hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false, E>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,              \
+                     (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,        \
+                     (const unsigned short*)a->d_roff, (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, \
+                     X, Y, (const double*)nullptr, (double*)nullptr, rhs, diag, omega)
+  if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else MXG_CS_EPI(0);
+#undef MXG_CS_EPI
+  if (hipGetLastError() != hipSuccess) { mxg_set_error("mxg_dev_csr_apply_epi: launch failed"); return 2; }
   return 0;
 }
 

@@ -156,7 +156,8 @@ struct mxg_mg {
   mxg_ctx* ctx = nullptr;
   int nlevels = 0;
   std::vector<mxg_csr*> A, P, R;
-  std::vector<mxg_mv*> r, z, t;       // per level: right-hand side, correction, scratch
+  std::vector<mxg_mv*> r, z, t;       // per level: right-hand side, correction, scratch (t doubles as the
+                                      // ping-pong partner of z for the fused sweeps)
   int pre = 2, post = 2, coarse = 20;
   double omega = 0.7, cscale = 1.9;
 };
@@ -201,12 +202,16 @@ int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
     if (s == 0 && zero_guess) {
       hipLaunchKernelGGL(k_jac_first, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag,
                          mg->omega, (const double*)mg->r[l]->colptr(0), mg->z[l]->colptr(0));
-    } else {
-      MXG_TRY(mxg_csr_apply(c, A, mg->z[l], mg->t[l]));
-      hipLaunchKernelGGL(k_jac_step, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag,
-                         mg->omega, (const double*)mg->r[l]->colptr(0), (const double*)mg->t[l]->colptr(0),
-                         mg->z[l]->colptr(0));
+      continue;
     }
+    // fused sweep on a compressed level: t = z + omega D^-1 (r - A z) in the product's epilogue, then swap
+    const int rc = mxg_dev_csr_apply_epi(c, A, mg->z[l], mg->t[l], 1, mg->r[l]->colptr(0), A->d_diag, mg->omega);
+    if (rc == 0) { std::swap(mg->z[l], mg->t[l]); continue; }
+    if (rc != 1) return 1;
+    MXG_TRY(mxg_csr_apply(c, A, mg->z[l], mg->t[l]));
+    hipLaunchKernelGGL(k_jac_step, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag,
+                       mg->omega, (const double*)mg->r[l]->colptr(0), (const double*)mg->t[l]->colptr(0),
+                       mg->z[l]->colptr(0));
   }
   MXG_HIP(hipGetLastError());
   return 0;
@@ -218,9 +223,13 @@ int mg_cycle(mxg_mg* mg, int l) {
   const long long n = mg->A[l]->nrows;
   const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
   MXG_TRY(mg_smooth(mg, l, mg->pre, true));
-  MXG_TRY(mxg_csr_apply(c, mg->A[l], mg->z[l], mg->t[l]));                       // t = A z
-  hipLaunchKernelGGL(k_resid, dim3(grid), dim3(256), 0, c->stream, n, (const double*)mg->r[l]->colptr(0),
-                     mg->t[l]->colptr(0));                                        // t = r - A z
+  const int rc = mxg_dev_csr_apply_epi(c, mg->A[l], mg->z[l], mg->t[l], 2, mg->r[l]->colptr(0), nullptr, 0.0);   // t = r - A z
+  if (rc > 1) return 1;
+  if (rc == 1) {
+    MXG_TRY(mxg_csr_apply(c, mg->A[l], mg->z[l], mg->t[l]));                     // t = A z
+    hipLaunchKernelGGL(k_resid, dim3(grid), dim3(256), 0, c->stream, n, (const double*)mg->r[l]->colptr(0),
+                       mg->t[l]->colptr(0));                                      // t = r - A z
+  }
   MXG_TRY(mxg_csr_apply(c, mg->R[l], mg->t[l], mg->r[l + 1]));                    // restrict
   MXG_TRY(mg_cycle(mg, l + 1));
   MXG_TRY(mxg_csr_apply(c, mg->P[l], mg->z[l + 1], mg->t[l]));                    // prolong
