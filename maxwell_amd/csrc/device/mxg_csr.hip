@@ -644,7 +644,8 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
       __syncthreads();
       if (t == 0) {
         double tr = 0.0;
-        for (int q = 0; q < SB; ++q) tr += svtab[q];
+#pragma unroll 4
+        for (int q = 0; q < SB; ++q) tr += svtab[q];   // (full unrolling of this cold loop would cost 256 VGPRs)
         Y.col(j)[d.r0] = cs_epilogue<EPI>(tr, d.r0, x, rhs, diag, omega);
         if (DOT && j == 0) partial[b] = tr * xdot[d.r0];
       }
@@ -677,7 +678,8 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     }
   }
   __syncthreads();
-  for (int j = 0; j < X.k; ++j) {
+#pragma unroll 1
+  for (int j = 0; j < X.k; ++j) {     // columns one after the other: unrolling this loop costs the occupancy
     const double* __restrict__ x = X.col(j);
     double sum[RPT];
     if (packed) {
@@ -700,6 +702,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
 #pragma unroll
         for (int i = 0; i < CH; ++i)
           if (o0[r] + i < o1[r]) sum[r] += v[r][i] * xv[r][i];
+#pragma unroll 1
         for (int q = o0[r] + CH; q < o1[r]; ++q) {       // longer rows: the tail, in storage order
           const unsigned code = scode[q];
           sum[r] += svtab[svid[q]] * x[sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u))];
@@ -709,6 +712,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         sum[r] = 0.0;
+#pragma unroll 1
         for (long long q = d.base + o0[r]; q < d.base + o1[r]; ++q) sum[r] += vals[q] * x[colidx[q]];
       }
     }
