@@ -617,13 +617,15 @@ __device__ inline double cs_epilogue(double ax, long long row, const double* __r
 // per wave at the same occupancy - the packed stream leaves the kernel latency-bound, not HBM-bound
 // (A/B at 256^3: 1 row/thread 0.234 ms, 2 rows 0.203 ms, 4 rows 0.313 ms).
 constexpr int CS_RPT = 2;
+// One column per launch (a block of k vectors is k launches: the packed stream is cheap to re-read, and
+// the single-column body keeps 16 waves per CU resident).
 template <typename CFG, int CH, bool DOT, int EPI = 0>
 __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     const CsDesc* __restrict__ desc, long long nblocks, const unsigned char* __restrict__ stream,
-    const unsigned short* __restrict__ roff, const long long* __restrict__ rowptr,
-    const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y,
+    const unsigned short* __restrict__ roff, const int* __restrict__ colidx, const double* __restrict__ vals,
+    const double* __restrict__ x, double* __restrict__ y,
     const double* __restrict__ xdot, double* __restrict__ partial,
-    const double* __restrict__ rhs = nullptr, const double* __restrict__ diag = nullptr, double omega = 0.0) {
+    const double* __restrict__ rhs, const double* __restrict__ diag, double omega) {
   constexpr int RPT = CS_RPT, SB = CFG::SBLK / RPT;
   __shared__ __attribute__((aligned(16))) unsigned short scode[CFG::NNZ_BLK];
   __shared__ __attribute__((aligned(16))) unsigned char svid[CFG::NNZ_BLK];
@@ -635,20 +637,17 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
   const CsDesc d = desc[b];
   const int t = threadIdx.x;
   if (d.nnzb > CFG::NNZ_CAP) {     // one over-long row: whole workgroup, fixed-order combine (as k_spmv_rowgather)
-    for (int j = 0; j < X.k; ++j) {
-      const double* x = X.col(j);
-      double sr = 0.0;
-      for (long long q = d.base + t; q < d.base + d.nnzb; q += SB) sr += vals[q] * x[colidx[q]];
-      if (j > 0) __syncthreads();
-      svtab[t] = sr;
-      __syncthreads();
-      if (t == 0) {
-        double tr = 0.0;
+    double sr = 0.0;
+#pragma unroll 1
+    for (long long q = d.base + t; q < d.base + d.nnzb; q += SB) sr += vals[q] * x[colidx[q]];
+    svtab[t] = sr;
+    __syncthreads();
+    if (t == 0) {
+      double tr = 0.0;
 #pragma unroll 4
-        for (int q = 0; q < SB; ++q) tr += svtab[q];   // (full unrolling of this cold loop would cost 256 VGPRs)
-        Y.col(j)[d.r0] = cs_epilogue<EPI>(tr, d.r0, x, rhs, diag, omega);
-        if (DOT && j == 0) partial[b] = tr * xdot[d.r0];
-      }
+      for (int q = 0; q < SB; ++q) tr += svtab[q];   // (full unrolling of this cold loop would cost 256 VGPRs)
+      y[d.r0] = cs_epilogue<EPI>(tr, d.r0, x, rhs, diag, omega);
+      if (DOT) partial[b] = tr * xdot[d.r0];
     }
     return;
   }
@@ -657,14 +656,16 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     const unsigned char* sp = stream + d.soff;
     if (t < CS_SEGS) sseg[t] = nt_load(reinterpret_cast<const int*>(sp) + t);
     const double* vt = reinterpret_cast<const double*>(sp + CS_SEGS * 4);
+#pragma unroll 1
     for (int p = t; p < d.nval; p += SB) svtab[p] = nt_load(vt + p);
     const int nvpad = (d.nval + 1) & ~1;
     const uint4v* cp = reinterpret_cast<const uint4v*>(sp + CS_SEGS * 4 + nvpad * 8);
     const int ncode16 = (d.nnzb + 7) >> 3;            // 16-byte pieces of the code array (8 codes each)
+#pragma unroll 1
     for (int p = t; p < ncode16; p += SB) reinterpret_cast<uint4v*>(scode)[p] = nt_load(cp + p);
     const uint4v* ip = cp + ncode16;
     const int nid16 = (d.nnzb + 15) >> 4;
-    for (int p = t; p < nid16; p += SB) reinterpret_cast<uint4v*>(svid)[p] = nt_load(ip + p);
+    if (t < nid16) reinterpret_cast<uint4v*>(svid)[t] = nt_load(ip + t);   // <= 128 pieces
   }
   int o0[RPT], o1[RPT];
 #pragma unroll
@@ -678,63 +679,59 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     }
   }
   __syncthreads();
-#pragma unroll 1
-  for (int j = 0; j < X.k; ++j) {     // columns one after the other: unrolling this loop costs the occupancy
-    const double* __restrict__ x = X.col(j);
-    double sum[RPT];
-    if (packed) {
-      // first CH entries of every row: all gathers of the thread's rows are issued before any product
-      double v[RPT][CH], xv[RPT][CH];
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        sum[r] = 0.0;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const bool on = o0[r] + i < o1[r];
-          const unsigned code = on ? scode[o0[r] + i] : 0u;
-          const int cc = on ? sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u)) : 0;
-          v[r][i] = on ? svtab[svid[o0[r] + i]] : 0.0;
-          xv[r][i] = on ? x[cc] : 0.0;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-          if (o0[r] + i < o1[r]) sum[r] += v[r][i] * xv[r][i];
-#pragma unroll 1
-        for (int q = o0[r] + CH; q < o1[r]; ++q) {       // longer rows: the tail, in storage order
-          const unsigned code = scode[q];
-          sum[r] += svtab[svid[q]] * x[sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u))];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        sum[r] = 0.0;
-#pragma unroll 1
-        for (long long q = d.base + o0[r]; q < d.base + o1[r]; ++q) sum[r] += vals[q] * x[colidx[q]];
-      }
-    }
-    double part = 0.0;
+  double sum[RPT];
+  if (packed) {
+    // first CH entries of every row: all gathers of the thread's rows are issued before any product
+    double v[RPT][CH], xv[RPT][CH];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      const int row = t + r * SB;
-      if (row < d.nr) {
-        __builtin_nontemporal_store(cs_epilogue<EPI>(sum[r], d.r0 + row, x, rhs, diag, omega), Y.col(j) + d.r0 + row);
-        if (DOT && j == 0) part += sum[r] * xdot[d.r0 + row];
+      sum[r] = 0.0;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const bool on = o0[r] + i < o1[r];
+        const unsigned code = on ? scode[o0[r] + i] : 0u;
+        const int cc = on ? sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u)) : 0;
+        v[r][i] = on ? svtab[svid[o0[r] + i]] : 0.0;
+        xv[r][i] = on ? x[cc] : 0.0;
       }
     }
-    if (DOT && j == 0) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-      if ((t & 63) == 0) sred[t >> 6] = part;
-      __syncthreads();
-      if (t == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < SB / 64; ++w) tot += sred[w];
-        partial[b] = tot;
+    for (int r = 0; r < RPT; ++r) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+        if (o0[r] + i < o1[r]) sum[r] += v[r][i] * xv[r][i];
+#pragma unroll 1
+      for (int q = o0[r] + CH; q < o1[r]; ++q) {       // longer rows: the tail, in storage order
+        const unsigned code = scode[q];
+        sum[r] += svtab[svid[q]] * x[sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u))];
       }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      sum[r] = 0.0;
+#pragma unroll 1
+      for (long long q = d.base + o0[r]; q < d.base + o1[r]; ++q) sum[r] += vals[q] * x[colidx[q]];
+    }
+  }
+  double part = 0.0;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int row = t + r * SB;
+    if (row < d.nr) {
+      __builtin_nontemporal_store(cs_epilogue<EPI>(sum[r], d.r0 + row, x, rhs, diag, omega), y + d.r0 + row);
+      if (DOT) part += sum[r] * xdot[d.r0 + row];
+    }
+  }
+  if (DOT) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((t & 63) == 0) sred[t >> 6] = part;
+    __syncthreads();
+    if (t == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < SB / 64; ++w) tot += sred[w];
+      partial[b] = tot;
     }
   }
 }
@@ -1345,10 +1342,11 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
   if ((a->kernel & 0x1000000) && !a->is_complex && a->ncs > 0 && a->pipe_geo == 10) {
     const long long per = (a->ncs + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
-    hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
-                       (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
-                       (const unsigned short*)a->d_roff, (const long long*)a->d_rowptr, a->d_colidx, a->d_vals,
-                       X, Y, (const double*)nullptr, (double*)nullptr);
+    for (int j = 0; j < X.k; ++j)
+      hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
+                         (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
+                         (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(j), Y.col(j),
+                         (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0);
   } else if ((a->kernel & 0x30000) && !a->is_complex && a->npipe > 0) {
     const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
@@ -1434,8 +1432,8 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
 #define MXG_CS_EPI(E)                                                                                          \
   hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false, E>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,     \
                      (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,        \
-                     (const unsigned short*)a->d_roff, (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, \
-                     X, Y, (const double*)nullptr, (double*)nullptr, rhs, diag, omega)
+                     (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0), \
+                     (const double*)nullptr, (double*)nullptr, rhs, diag, omega)
   if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else MXG_CS_EPI(0);
 #undef MXG_CS_EPI
   if (hipGetLastError() != hipSuccess) { mxg_set_error("mxg_dev_csr_apply_epi: launch failed"); return 2; }
@@ -1458,8 +1456,8 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
   if ((a->kernel & 0x1000000) && a->ncs == a->npipe)
     hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
                        (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
-                       (const unsigned short*)a->d_roff, (const long long*)a->d_rowptr, a->d_colidx, a->d_vals,
-                       X, Y, (const double*)x->colptr(0), a->d_dotpartial);
+                       (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0),
+                       (const double*)x->colptr(0), a->d_dotpartial, (const double*)nullptr, (const double*)nullptr, 0.0);
   else
   hipLaunchKernelGGL((k_spmv_rowgather<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,
                      (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr,
