@@ -23,8 +23,16 @@ class MxGrid {
 template <size_t DIM>
 class MxGridField {
  public:
-  MxGridField(std::string name, RCP<MxMap> map, std::vector<double> mask) : mName(name), mMap(map), mMask(mask) {}
+  MxGridField(std::string name, RCP<MxMap> map, std::vector<double> mask, int numComps = 3,
+              std::string fieldName = "", const int* res = nullptr)
+      : mName(name), mMap(map), mMask(mask), mNumComps(numComps), mFieldName(fieldName) {
+    for (int i = 0; i < 3; ++i) mRes[i] = res ? res[i] : 0;
+  }
   std::string getName() const { return mName; }
+  int getNumComps() const { return mNumComps; }
+  // the reference's per-class field name, used in output file names (src/MxYeeFitBField.cpp:13, ...)
+  std::string getFieldName() const { return mFieldName; }
+  int getResolution(int i) const { return mRes[i]; }
   RCP<MxMap> getMap() const { return mMap; }
   // zero the components that are in the map but unused (zero area fraction / zero BC factor);
   // src/MxGridField.cpp "zeroUnusedComponents", called from src/MxSolver.cpp:65
@@ -41,6 +49,9 @@ class MxGridField {
   std::string mName;
   RCP<MxMap> mMap;
   std::vector<double> mMask;
+  int mNumComps;
+  std::string mFieldName;
+  int mRes[3];
   mutable std::shared_ptr<MxMultiVector<double> > mMaskDev;
 };
 
@@ -75,7 +86,9 @@ class MxEMSim {
   void addField(const char* name, const mx::YeeField& f, std::vector<double> mask, RCP<MxComm> comm) {
     std::vector<MxIndex> g(f.gids.begin(), f.gids.end());
     RCP<MxMap> map = rcp(new MxMap(g, comm));
-    mFields[name] = std::make_shared<MxGridField<DIM> >(name, map, mask);
+    const std::string nm(name);
+    const char* cls = nm == "bfield" ? "YeeFitBField" : (nm == "efield" ? "YeeFitEField" : "YeeFitPsiField");
+    mFields[name] = std::make_shared<MxGridField<DIM> >(name, map, mask, f.ncomp, cls, mCfg.n);
   }
   mx::YeeConfig mCfg;
   MxGrid<DIM> mGrid;

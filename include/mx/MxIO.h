@@ -1,0 +1,67 @@
+// MxIO<DIM, Scalar>::save (reference src/MxIO.h, src/MxIO.cpp:167-222): one file per vector,
+// `mx<FieldName>_<name>_vecNN.h5`, dataset "real" (and "imag" for complex scalars) of shape
+// (Nx+1, Ny+1, Nz+1, ncomp), zero where the component is not in the field's map.  The global id of a
+// component is comp + ncomp * cellIndex with the cell index in C order over the node lattice
+// (src/MxGridField.hpp:142-145, src/MxGrid.h:98-113), so the file array is the vector scattered by global id.
+// Written through mxh_field_write: HDF5 when a library can be loaded at run time, NumPy `.npy` otherwise.
+#ifndef MX_IO_H
+#define MX_IO_H
+
+#include <cstdio>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "MxEMSim.h"
+#include "MxMultiVector.hpp"
+#include "mxh.h"
+
+#define MX_ABI_H(call, where) do { if ((call) != 0) { std::cout << where << ": " << mxh_last_error() << "\n"; throw 1; } } while (0)
+
+template <size_t DIM, typename Scalar>
+class MxIO {
+ public:
+  explicit MxIO(RCP<MxComm> comm) : mComm(comm) {}
+
+  // returns the paths written
+  std::vector<std::string> save(MxMultiVector<Scalar> const& fieldData, MxGridField<DIM> const& field, std::string name) {
+    std::vector<std::string> out;
+    if (fieldData.getMap()->getNodeNumIndices() != field.getMap()->getNodeNumIndices()) {
+      std::cout << "MxIO<DIM, Scalar>::save(fieldData, gridField, name): dist map of fieldData does not match that of gridField. Field save aborted.\n";
+      return out;
+    }
+    const int nc = field.getNumComps();
+    int64_t dims[4] = {field.getResolution(0) + 1, field.getResolution(1) + 1, field.getResolution(2) + 1, nc};
+    const size_t total = (size_t)(dims[0] * dims[1] * dims[2] * dims[3]);
+    const MxMap& map = *field.getMap();
+    const size_t nloc = map.getNodeNumIndices();
+    std::vector<Scalar> col;
+    std::vector<double> re(total), im;
+    if (ScalarTraits<Scalar>::isComplex) im.resize(total);
+    for (size_t vec = 0; vec < fieldData.getNumVecs(); ++vec) {
+      fieldData.getColumn(vec, col);
+      std::fill(re.begin(), re.end(), 0.0);
+      std::fill(im.begin(), im.end(), 0.0);
+      for (size_t l = 0; l < nloc; ++l) {
+        const size_t g = (size_t)map.getGlobalIndex(l);
+        re[g] = mxRe(col[l]);
+        if (ScalarTraits<Scalar>::isComplex) im[g] = mxIm(col[l]);
+      }
+      char stem[256], written[512];
+      std::snprintf(stem, sizeof stem, "mx%s_%s_vec%.2i", field.getFieldName().c_str(), name.c_str(), (int)vec);
+      MX_ABI_H(mxh_field_write(stem, "real", dims, re.data(), written, sizeof written), "MxIO::save");
+      out.push_back(written);
+      if (ScalarTraits<Scalar>::isComplex) {   // the reference puts "imag" into the same file; here: a second file
+        const std::string s2 = std::string(stem) + "_imag";
+        MX_ABI_H(mxh_field_write(s2.c_str(), "imag", dims, im.data(), written, sizeof written), "MxIO::save");
+        out.push_back(written);
+      }
+    }
+    return out;
+  }
+
+ private:
+  RCP<MxComm> mComm;
+};
+
+#endif

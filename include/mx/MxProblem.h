@@ -328,6 +328,8 @@ class MxProblem {
     solver->solve();
   }
 
+  // MxSolver::solve writes the eigenvector files like the reference (src/MxSolver.cpp:222-224)
+  void setSaveFields(bool on) { pList.set("io : save fields", on); }
   Teuchos::ParameterList const& getParameters() const { return pList; }
   mx::YeeConfig const& getConfig() const { return cfg; }
   std::string const& getName() const { return mName; }

@@ -5,6 +5,7 @@
 
 #include <iomanip>
 
+#include "MxIO.h"
 #include "MxMagWaveOp.h"
 
 // inner product operator of the eigenproblem: x -> M x with M = mRhs (dmA).  The shift-invert
@@ -96,6 +97,16 @@ class MxSolver {
     }
     mEEigVecs = rcp(new MxMultiVector<Scalar>(sim->getField("efield").getMap(), sol.numVecs));
     mwOpPtr->magToElec(*mBEigVecs, *mEEigVecs);
+    // src/MxSolver.cpp:222-224: the reference always writes the fields; here on request ("io : save fields",
+    // set by the `maxwell` command line) - 3 (N+1)^3 doubles per vector is 0.4 GB at 256^3
+    if (pList.get("io : save fields", false) && sim->getGrid().getComm()->numProc() == 1) {
+      MxIO<DIM, Scalar> io(sim->getGrid().getComm());
+      std::vector<std::string> fb = io.save(*mBEigVecs, sim->getField("bfield"), "eigVecs");
+      std::vector<std::string> fe = io.save(*mEEigVecs, sim->getField("efield"), "eigVecs");
+      mFieldFiles = fb;
+      mFieldFiles.insert(mFieldFiles.end(), fe.begin(), fe.end());
+      if (myPID == 0 && verb) for (auto const& f : mFieldFiles) std::cout << "Saved " << f << "\n";
+    }
   }
 
   // results (the reference only prints them)
@@ -107,6 +118,7 @@ class MxSolver {
   RCP<MxMultiVector<Scalar> > magneticEigenvectors() const { return mBEigVecs; }
   RCP<MxMultiVector<Scalar> > electricEigenvectors() const { return mEEigVecs; }
   double eigensolveSeconds() const { return mSolveSeconds; }
+  std::vector<std::string> const& fieldFiles() const { return mFieldFiles; }
   MxMagWaveOp<DIM, Scalar> const& waveOp() const { return *mwOpPtr; }
 
  private:
@@ -120,6 +132,7 @@ class MxSolver {
   RCP<MV> mInitVec;
   std::vector<MxComplex> mEigVals, mEigFreqs;
   std::vector<double> eigErrs, divErrs;
+  std::vector<std::string> mFieldFiles;
   RCP<MxMultiVector<Scalar> > mBEigVecs, mEEigVecs;
   RCP<Anasazi::BasicEigenproblem<Scalar, MV, OP> > mEigProb;
   RCP<Anasazi::SolverManager<Scalar, MV, OP> > mEigMgr;

@@ -156,6 +156,17 @@ int mxh_problem_sim(mxh_problem* p, mxh_sim** sim);
  * valid while the problem lives.  `verbose` < 0 keeps the deck's "output" level. */
 int mxh_problem_solver(mxg_ctx* ctx, mxh_problem* p, int verbose, mxh_solver** out);
 
+/* ---------------------------------------------------------------------------------------
+ * Field output in the layout of MxIO::save (src/MxIO.cpp:94-222): a 4-d array of doubles
+ * (Nx+1, Ny+1, Nz+1, ncomp) per vector.  `<stem>.h5` with the named dataset when an HDF5 library
+ * can be loaded at run time (it is not a build dependency), otherwise `<stem>.npy`.
+ * ------------------------------------------------------------------------------------- */
+int mxh_hdf5_available(void);
+int mxh_field_write(const char* stem, const char* dataset, const int64_t dims[4], const double* data,
+                    char* written, size_t written_len);
+/* read a dataset back (dims always; data when non-NULL and capacity >= product of dims) */
+int mxh_field_read_h5(const char* path, const char* dataset, int64_t dims[4], double* data, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 DEVICE_SOURCES = ["mxg_ctx.hip", "mxg_mv.hip", "mxg_csr.hip", "mxg_solve.hip"]
 HOST_SOURCES = ["mx_geometry.cpp", "mx_yee.cpp", "mxh_sim.cpp", "mxh_mg.cpp", "mxh_solver.cpp",
-                "mxh_problem.cpp"]
+                "mxh_problem.cpp", "mxh_io.cpp"]
 CLI_SOURCE = "maxwell.cpp"          # the reference's `maxwell --infile=deck.mx` entry point
 
 
@@ -90,7 +90,7 @@ def build_host(force=False):
     # -ffp-contract=off: assembled matrix values must not depend on FMA contraction
     cmd = ["g++", "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-I" + INCLUDE, "-I" + os.path.join(INCLUDE, "mx"), "-I" + src_dir] + HOST_SOURCES + \
-          ["-o", target, "-L" + LIBDIR, "-lmxg", "-Wl,-rpath,$ORIGIN"]
+          ["-o", target, "-L" + LIBDIR, "-lmxg", "-ldl", "-Wl,-rpath,$ORIGIN"]
     _run(cmd, src_dir)
     # the command-line front end, next to the libraries it links
     cli = os.path.join(LIBDIR, "maxwell")

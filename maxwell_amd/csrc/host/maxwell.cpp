@@ -3,9 +3,9 @@
 // src/MxSolver.cpp:176-196.
 //
 // Differences from the reference binary: no MPI::Init (one process drives one GPU; multi-GPU runs go
-// through bench.py / the Python launcher), 1-D/2-D decks are rejected instead of instantiated, and
-// no HDF5 eigenvector files are written (MxIO is out of scope) - `--eigvals=FILE` writes
-// the frequencies as text instead.
+// through bench.py / the Python launcher), 1-D/2-D decks are rejected instead of instantiated; the
+// eigenvector files of MxIO::save are written as HDF5 when a libhdf5 can be loaded at run time and as
+// `.npy` otherwise; `--eigvals=FILE` additionally writes the frequencies as text.
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -17,7 +17,7 @@
 int main(int argc, char* argv[]) {
   std::string inFile, eigFile;
   int device = 0;
-  bool strict = true;
+  bool strict = true, fields = true;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a.compare(0, 9, "--infile=") == 0) inFile = a.substr(9);
@@ -25,12 +25,14 @@ int main(int argc, char* argv[]) {
     else if (a.compare(0, 10, "--eigvals=") == 0) eigFile = a.substr(10);
     else if (a.compare(0, 9, "--device=") == 0) device = atoi(a.substr(9).c_str());
     else if (a == "--fix-periodic-wrap") strict = false;
+    else if (a == "--no-fields") fields = false;
     else if (a == "--help" || a == "-h") {
       std::cout << "Usage: " << argv[0] << " [options]\n  options:\n"
                 << "  --help               Prints this help message\n"
                 << "  --infile    string   XML format input file.\n"
                 << "  --eigvals   string   write 'index real imag error' lines of the eigenfrequencies (Hz)\n"
                 << "  --device    int      GPU ordinal (default 0)\n"
+                << "  --no-fields          do not write the eigenvector files mxYeeFit{B,E}Field_eigVecs_vecNN.h5 (.npy without HDF5)\n"
                 << "  --fix-periodic-wrap  keep the wrap-around entries the reference drops from curlE on\n"
                 << "                       periodic axes (DESIGN.md section 7); default: reference behaviour\n";
       return 0;
@@ -62,6 +64,7 @@ int main(int argc, char* argv[]) {
     RCP<MxComm> myComm = rcp(new MxComm(device));
     {
       MxProblem<3> prob3d(xmlObj, myComm, strict);
+      prob3d.setSaveFields(fields);
       prob3d.solve();
       if (eigFile != "") {
         std::ofstream out(eigFile.c_str());

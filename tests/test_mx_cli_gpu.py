@@ -65,7 +65,7 @@ def test_maxwell_cli_pillbox_deck(built, tmp_path):
     want = _sparse_physical_modes(deck, 3)   # TM010, TE111 x2 (the pair is degenerate: either copy is fine)
     eig = tmp_path / "eig.txt"
     r = subprocess.run([CLI, "--infile=" + os.path.join(GOLDEN, "pillbox.mx"), "--eigvals=" + str(eig)],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Running simulation: Simulation" in r.stdout
     assert "========= Eigenfrequencies (Hz) =========" in r.stdout
@@ -80,6 +80,26 @@ def test_maxwell_cli_pillbox_deck(built, tmp_path):
     assert np.all(saved[:, 2] == 0.0) and np.all(saved[:, 3] < 1e-4)
     tm010 = (2.404825557695773 / 0.4) ** 2
     assert abs(k2[0] - tm010) / tm010 < 6e-3                           # O(h^2) at resolution 18
+    # eigenvector files of MxIO::save (src/MxSolver.cpp:222-224, src/MxIO.cpp:167-222): (N+1)^3 x 3 per vector
+    files = sorted(os.listdir(str(tmp_path)))
+    for field in ("YeeFitBField", "YeeFitEField"):
+        for vec in (0, 1):
+            stem = "mx%s_eigVecs_vec%02d" % (field, vec)
+            hit = [f for f in files if f.startswith(stem)]
+            assert len(hit) == 1, (stem, files)
+            path = os.path.join(str(tmp_path), hit[0])
+            if hit[0].endswith(".npy"):
+                arr = np.load(path)
+            else:
+                import ctypes as C
+                from maxwell_amd import _lib
+                lib = _lib.load_mxhost()
+                dims = (C.c_int64 * 4)()
+                arr = np.empty(19 * 19 * 19 * 3)
+                assert lib.mxh_field_read_h5(path.encode(), b"real", dims, arr.ctypes.data_as(_lib.c_dp), arr.size) == 0
+                arr = arr.reshape(tuple(dims))
+            assert arr.shape == (19, 19, 19, 3)
+            assert np.abs(arr).max() > 0 and np.all(arr[0, 0, :, :] == 0.0)     # metal corner column: not in the map
 
 
 def test_maxwell_cli_errors(built, tmp_path):
