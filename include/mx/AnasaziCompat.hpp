@@ -145,11 +145,10 @@ inline void symEig(int n, std::vector<double>& A, std::vector<double>& w, std::v
 // Householder reduction to Hessenberg form, single-shift QR with Givens rotations to the complex Schur
 // form T = Q^H A Q, eigenvectors of T by back substitution, X = Q Y (columns of unit 2-norm).
 // Dense O(n^3); n is the Krylov basis size (<= a few hundred).
-inline bool genEig(int n, const std::vector<double>& A, std::vector<std::complex<double> >& w,
+inline bool genEig(int n, const std::vector<std::complex<double> >& A, std::vector<std::complex<double> >& w,
                    std::vector<std::complex<double> >& X) {
   typedef std::complex<double> C;
-  std::vector<C> H((size_t)n * n), Q((size_t)n * n, C(0.0));
-  for (size_t i = 0; i < (size_t)n * n; ++i) H[i] = C(A[i], 0.0);
+  std::vector<C> H(A.begin(), A.begin() + (size_t)n * n), Q((size_t)n * n, C(0.0));
   for (int i = 0; i < n; ++i) Q[i + (size_t)n * i] = C(1.0);
   auto h = [&](int i, int j) -> C& { return H[i + (size_t)n * j]; };
   auto q = [&](int i, int j) -> C& { return Q[i + (size_t)n * j]; };
@@ -269,6 +268,13 @@ inline bool genEig(int n, const std::vector<double>& A, std::vector<std::complex
   return true;
 }
 
+inline bool genEig(int n, const std::vector<double>& A, std::vector<std::complex<double> >& w,
+                   std::vector<std::complex<double> >& X) {
+  std::vector<std::complex<double> > Ac((size_t)n * n);
+  for (size_t i = 0; i < (size_t)n * n; ++i) Ac[i] = std::complex<double>(A[i], 0.0);
+  return genEig(n, Ac, w, X);
+}
+
 }  // namespace detail
 
 // Thick-restart block Krylov-Schur (Hermitian).  Parameters as set by MxSolver
@@ -287,12 +293,11 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
     tol_ = pl.get("Convergence Tolerance", 1.0e-8);
     verb_ = pl.get("Verbosity", 0);
     if (!problem->isProblemSet()) throw std::invalid_argument("BlockKrylovSchurSolMgr: problem not set");
-    if (!problem->isHermitian() && ScalarTraits<Scalar>::isComplex)
-      throw std::invalid_argument("BlockKrylovSchurSolMgr: the non-Hermitian path is built for real scalars only");
   }
   int getNumIters() const { return iters_; }
 
   ReturnType solve() {
+    if (ScalarTraits<Scalar>::isComplex) return solveComplex((Scalar*)0);   // Hermitian or not: general complex path
     if (!prob_->isHermitian()) return solveGeneral();
     const int b = blockSize_, nev = prob_->getNEV();
     const int maxdim = std::max(numBlocks_ * b, nev + 2 * b);     // Krylov basis size before a restart
@@ -615,6 +620,164 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
       ++restarts;
     }
   }
+
+  ReturnType solveComplex(double*) { throw std::logic_error("solveComplex on real scalars"); }
+
+  // Complex scalars (Bloch phase shifts, lossy materials): block Arnoldi with a complex projected matrix,
+  // Ritz pairs from its eigen-decomposition, restart on an orthonormal basis of the wanted Ritz vectors
+  // (A (V Y) = (V Y) S + Q (R Y_last), S = Y^H H Y).  Used for Hermitian problems as well.
+  ReturnType solveComplex(std::complex<double>*) {
+    typedef std::complex<double> C;
+    const int b = blockSize_, nev = prob_->getNEV();
+    const int maxdim = std::max(numBlocks_ * b, nev + 2 * b + 1);
+    const int cap = maxdim + b;
+    RCP<OP> op = prob_->getOperator(), M = prob_->getM();
+    RCP<MV> init = prob_->getInitVec();
+    if (init->GetNumberVecs() < b) throw std::invalid_argument("BlockKrylovSchurSolMgr: initial block smaller than the block size");
+    std::unique_ptr<MV> V(init->Clone(cap + b)), W(init->Clone(b));
+    std::unique_ptr<MV> MW(M.is_null() ? nullptr : init->Clone(b));
+    const int ldh = cap + b;
+    std::vector<C> H((size_t)ldh * cap, C(0.0));
+    auto Hat = [&](int i, int j) -> C& { return H[i + (size_t)ldh * j]; };
+    Dense R(b, b);
+    {
+      std::unique_ptr<const MV> i0(init->CloneView(range(0, b)));
+      W->MvAddMv(ScalarTraits<Scalar>::one(), *i0, ScalarTraits<Scalar>::zero(), *i0);
+    }
+    if (orthonormalize(*V, 0, *W, MW.get(), M, R) < b)
+      throw std::runtime_error("BlockKrylovSchur: start block is rank deficient");
+    setCols(*V, 0, *W);
+    int k = b, restarts = 0, nconv = 0;
+    iters_ = 0;
+    while (true) {
+      bool breakdown = false;
+      while (k - b < maxdim) {
+        {
+          std::unique_ptr<const MV> Vact(V->CloneView(range(k - b, b)));
+          op->Apply(*Vact, *W);
+        }
+        ++iters_;
+        std::vector<double> scale(b);
+        for (int j = 0; j < b; ++j) {
+          std::unique_ptr<MV> wj(W->CloneViewNonConst(range(j, 1)));
+          std::unique_ptr<MV> mwj(MW ? MW->CloneViewNonConst(range(0, 1)) : nullptr);
+          scale[j] = mnorm(*wj, mwj.get(), M);
+        }
+        Dense h(k, b), h2(k, b);
+        std::unique_ptr<const MV> Vk(V->CloneView(range(0, k)));
+        innerProd(*Vk, *W, MW.get(), M, h);
+        W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h, ScalarTraits<Scalar>::one());
+        innerProd(*Vk, *W, MW.get(), M, h2);
+        W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h2, ScalarTraits<Scalar>::one());
+        for (int j = 0; j < b; ++j)
+          for (int i = 0; i < k; ++i) Hat(i, k - b + j) = C(h(i, j)) + C(h2(i, j));
+        const int rank = orthonormalize(*V, k, *W, MW.get(), M, R, &scale);
+        for (int j = 0; j < b; ++j) for (int r = 0; r < b; ++r) Hat(k + r, k - b + j) = C(R(r, j));
+        setCols(*V, k, *W);
+        k += b;
+        if (rank < b) { breakdown = true; break; }
+      }
+      const int m = k - b;
+      std::vector<C> A((size_t)m * m);
+      for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) A[i + (size_t)m * j] = Hat(i, j);
+      std::vector<C> w, X;
+      if (!detail::genEig(m, A, w, X)) throw std::runtime_error("BlockKrylovSchur: dense QR iteration did not converge");
+      std::vector<int> order(m);
+      std::iota(order.begin(), order.end(), 0);
+      sortRitzComplex(w, order);
+      std::vector<double> resid(m);
+      for (int c = 0; c < m; ++c) {
+        const int i = order[c];
+        double r2 = 0.0;
+        for (int r = 0; r < b; ++r) {
+          C sum(0.0);
+          for (int qq = 0; qq < b; ++qq) sum += Hat(m + r, m - b + qq) * X[(m - b + qq) + (size_t)m * i];
+          r2 += std::norm(sum);
+        }
+        resid[c] = std::sqrt(r2);
+      }
+      nconv = 0;
+      while (nconv < std::min(nev, m) && resid[nconv] <= tol_ * std::abs(w[order[nconv]])) ++nconv;
+      if (verb_ > 0) {
+        std::cout << "BlockKrylovSchur (complex): restart " << restarts << ", basis " << m << ", converged " << nconv << "/" << nev << "\n";
+        for (int c = 0; c < std::min(nev, m); ++c)
+          std::cout << "   theta = " << w[order[c]] << "   residual = " << resid[c] << "\n";
+      }
+      const bool done = nconv >= nev || restarts >= maxRestarts_ || breakdown;
+      int keep = done ? std::min(nev, m) : std::max(nev + b, (nev + m) / 2);
+      if (!done && keep > m - b) keep = m - b;
+      if (keep < 1) keep = 1;
+      // orthonormal basis of the wanted Ritz vectors (modified Gram-Schmidt, twice)
+      std::vector<std::vector<C> > Y((size_t)keep, std::vector<C>((size_t)m));
+      for (int c = 0; c < keep; ++c) for (int i = 0; i < m; ++i) Y[c][i] = X[i + (size_t)m * order[c]];
+      if (!done)
+        for (int c = 0; c < keep; ++c) {
+          for (int pass = 0; pass < 2; ++pass)
+            for (int p = 0; p < c; ++p) {
+              C d(0.0);
+              for (int i = 0; i < m; ++i) d += std::conj(Y[p][i]) * Y[c][i];
+              for (int i = 0; i < m; ++i) Y[c][i] -= d * Y[p][i];
+            }
+          double nrm = 0.0;
+          for (int i = 0; i < m; ++i) nrm += std::norm(Y[c][i]);
+          nrm = std::sqrt(nrm);
+          if (!(nrm > 1e-13)) throw std::runtime_error("BlockKrylovSchur: wanted Ritz vectors are linearly dependent");
+          for (int i = 0; i < m; ++i) Y[c][i] /= nrm;
+        }
+      Dense Zk(m, keep);
+      for (int c = 0; c < keep; ++c) for (int i = 0; i < m; ++i) Zk(i, c) = fromComplex(Y[c][i], (Scalar*)0);
+      std::unique_ptr<MV> Yv(init->Clone(keep));
+      {
+        std::unique_ptr<const MV> Vm(V->CloneView(range(0, m)));
+        Yv->MvTimesMatAddMv(ScalarTraits<Scalar>::one(), *Vm, Zk, ScalarTraits<Scalar>::zero());
+      }
+      if (done) {
+        Eigensolution<Scalar, MV> sol;
+        sol.numVecs = keep;
+        sol.Evecs = RCP<MV>(Yv.release());
+        for (int c = 0; c < keep; ++c) {
+          Value<double> v; v.realpart = w[order[c]].real(); v.imagpart = w[order[c]].imag();
+          sol.Evals.push_back(v);
+          sol.index.push_back(0);
+        }
+        prob_->setSolution(sol);
+        numConverged_ = nconv;
+        residuals_.assign(resid.begin(), resid.begin() + keep);
+        return nconv >= nev ? Converged : Unconverged;
+      }
+      std::vector<C> HY((size_t)m * keep, C(0.0)), S((size_t)keep * keep, C(0.0)), Bt((size_t)b * keep, C(0.0));
+      for (int c = 0; c < keep; ++c)
+        for (int j = 0; j < m; ++j) {
+          const C yj = Y[c][j];
+          for (int i = 0; i < m; ++i) HY[i + (size_t)m * c] += Hat(i, j) * yj;
+        }
+      for (int c = 0; c < keep; ++c)
+        for (int p = 0; p < keep; ++p) {
+          C d(0.0);
+          for (int i = 0; i < m; ++i) d += std::conj(Y[p][i]) * HY[i + (size_t)m * c];
+          S[p + (size_t)keep * c] = d;
+        }
+      for (int c = 0; c < keep; ++c)
+        for (int r = 0; r < b; ++r) {
+          C d(0.0);
+          for (int qq = 0; qq < b; ++qq) d += Hat(m + r, m - b + qq) * Y[c][m - b + qq];
+          Bt[r + (size_t)b * c] = d;
+        }
+      std::unique_ptr<MV> Qb(V->CloneCopy(range(m, b)));
+      setCols(*V, 0, *Yv);
+      setCols(*V, keep, *Qb);
+      std::fill(H.begin(), H.end(), C(0.0));
+      for (int c = 0; c < keep; ++c) {
+        for (int p = 0; p < keep; ++p) Hat(p, c) = S[p + (size_t)keep * c];
+        for (int r = 0; r < b; ++r) Hat(keep + r, c) = Bt[r + (size_t)b * c];
+      }
+      k = keep + b;
+      ++restarts;
+    }
+  }
+
+  static double fromComplex(const std::complex<double>& z, double*) { return z.real(); }
+  static std::complex<double> fromComplex(const std::complex<double>& z, std::complex<double>*) { return z; }
 
   int getNumConverged() const { return numConverged_; }
 

@@ -13,7 +13,7 @@ class MxEMOps {
   }
   // primitive operators straight from the assembler (src/MxEMOps.cpp:39-168)
   void setSingleOps() {
-    const mx::YeeAssembler<double>& a = mSim->getAssembler();
+    const mx::YeeAssembler<Scalar>& a = mSim->assemblerFor((Scalar*)0);
     RCP<MxMap> b = mSim->getField("bfield").getMap(), e = mSim->getField("efield").getMap(),
                p = mSim->getField("psifield").getMap();
     insert("curlE", b, e, a.curlE());
@@ -71,15 +71,8 @@ class MxEMOps {
   }
   void saveOps() const { for (auto& e : mOps) e.second->save("Mx" + e.first); }
  private:
-  void insert(const char* name, RCP<MxMap> rows, RCP<MxMap> cols, mx::Csr<double> const& m) {
-    mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, convert(m)));
-  }
-  static mx::Csr<Scalar> convert(mx::Csr<double> const& m) {
-    mx::Csr<Scalar> c;
-    c.nrows = m.nrows; c.ncols = m.ncols; c.rowptr = m.rowptr; c.col = m.col;
-    c.val.resize(m.val.size());
-    for (size_t i = 0; i < m.val.size(); ++i) c.val[i] = Scalar(m.val[i]);
-    return c;
+  void insert(const char* name, RCP<MxMap> rows, RCP<MxMap> cols, mx::Csr<Scalar> const& m) {
+    mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, m));
   }
   int pid;
   RCP<MxEMSim<DIM> > mSim;

@@ -58,17 +58,23 @@ class MxGridField {
 template <size_t DIM>
 class MxEMSim {
  public:
+  // A problem with Bloch phase shifts is assembled in complex arithmetic (src/MxGridField.cpp:34-38,157-188);
+  // everything else in real arithmetic.
   MxEMSim(mx::YeeConfig const& cfg, RCP<MxComm> comm, Teuchos::ParameterList pList = Teuchos::ParameterList(),
           std::shared_ptr<mx::YeeAssembler<double> > assembler = nullptr)
-      : mCfg(cfg), mGrid(comm), mPList(pList),
-        mAsm(assembler ? assembler : std::make_shared<mx::YeeAssembler<double> >(cfg)) {
+      : mCfg(cfg), mGrid(comm), mPList(pList) {
     static_assert(DIM == 3, "only the 3-D path is built");
-    addField("bfield", mAsm->bfield(), mAsm->usedMask(), comm);
-    addField("efield", mAsm->efield(), std::vector<double>(), comm);
-    addField("psifield", mAsm->psifield(), std::vector<double>(), comm);
-    if (hasDielectric()) mFields["dfield"] = mFields["efield"];   // dfield->setMap(efield), src/MxEMSim.cpp:196-197
+    mComplex = cfg.phaseShifts[0] != 0.0 || cfg.phaseShifts[1] != 0.0 || cfg.phaseShifts[2] != 0.0;
+    if (mComplex) {
+      mAsmC = std::make_shared<mx::YeeAssembler<MxComplex> >(cfg);
+      addFields(*mAsmC, comm);
+    } else {
+      mAsm = assembler ? assembler : std::make_shared<mx::YeeAssembler<double> >(cfg);
+      addFields(*mAsm, comm);
+    }
     mPList.set("has curl null", true);
   }
+  bool isComplex() const { return mComplex; }
   bool hasPEC() const { return (bool)mCfg.pec; }
   bool hasDielectric() const { return !mCfg.dielectrics.empty(); }
   bool hasMu() const { return false; }
@@ -81,8 +87,24 @@ class MxEMSim {
     if (it == mFields.end()) { std::cout << "MxEMSim<" << DIM << ">::getField: field '" << fieldName << "' not found."; throw 1; }
     return *it->second;
   }
-  const mx::YeeAssembler<double>& getAssembler() const { return *mAsm; }
+  const mx::YeeAssembler<double>& getAssembler() const {
+    if (!mAsm) { std::cout << "MxEMSim::getAssembler: the problem is complex (phase shifts); use the complex solver\n"; throw 1; }
+    return *mAsm;
+  }
+  // assembler in the solver's scalar type: a complex solve of a real problem assembles a complex copy on demand
+  const mx::YeeAssembler<double>& assemblerFor(double*) const { return getAssembler(); }
+  const mx::YeeAssembler<MxComplex>& assemblerFor(MxComplex*) const {
+    if (!mAsmC) mAsmC = std::make_shared<mx::YeeAssembler<MxComplex> >(mCfg);
+    return *mAsmC;
+  }
  private:
+  template <typename A>
+  void addFields(const A& a, RCP<MxComm> comm) {
+    addField("bfield", a.bfield(), a.usedMask(), comm);
+    addField("efield", a.efield(), std::vector<double>(), comm);
+    addField("psifield", a.psifield(), std::vector<double>(), comm);
+    if (hasDielectric()) mFields["dfield"] = mFields["efield"];   // dfield->setMap(efield), src/MxEMSim.cpp:196-197
+  }
   void addField(const char* name, const mx::YeeField& f, std::vector<double> mask, RCP<MxComm> comm) {
     std::vector<MxIndex> g(f.gids.begin(), f.gids.end());
     RCP<MxMap> map = rcp(new MxMap(g, comm));
@@ -93,7 +115,9 @@ class MxEMSim {
   mx::YeeConfig mCfg;
   MxGrid<DIM> mGrid;
   Teuchos::ParameterList mPList;
+  bool mComplex = false;
   std::shared_ptr<mx::YeeAssembler<double> > mAsm;
+  mutable std::shared_ptr<mx::YeeAssembler<MxComplex> > mAsmC;
   std::map<std::string, std::shared_ptr<MxGridField<DIM> > > mFields;
 };
 

@@ -255,20 +255,25 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mOpts.max_iters = mPList.get("linear solver : max iters", 0);
     mOpts.cheb_degree = 0; mOpts.lmin = 0; mOpts.lmax = 0; mOpts.mg = nullptr;
     if (mUseMg) {
-      if (mBMap->getComm()->numProc() > 1) {
-        if (pid == 0) std::cout << "MxMagWaveOp: multigrid is single-rank for now -> Jacobi.\n";
+      if (mBMap->getComm()->numProc() > 1 || ScalarTraits<Scalar>::isComplex) {
+        if (pid == 0) std::cout << "MxMagWaveOp: multigrid is single-rank and real for now -> Jacobi.\n";
         mOpts.precond = 1; mUseMg = false;
       } else {
-        const int sweeps = mPList.get("linear solver : amg : sweeps", 2);
-        const int levels = mPList.get("linear solver : amg : max levels", 10);
-        const mx::YeeAssembler<double>& a = mSim->getAssembler();
-        mxg_ctx* ctx = mBMap->getComm()->getCtx();
-        if (mVecMg) mxh_mg_destroy(mVecMg);
-        mVecMg = mxh_mg_build(ctx, mShiftedVecLapl->getHostCsr(), a.bfield(), a.config().n, 2000, levels, sweeps, 30, 0.7, 1.9);
-        if (mHasCurlNull && !mScaMg)
-          mScaMg = mxh_mg_build(ctx, mScaLapl->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.7, 1.9);
+        buildMultigrid((Scalar*)0);
       }
     }
+  }
+
+  void buildMultigrid(MxComplex*) {}
+  void buildMultigrid(double*) {
+    const int sweeps = mPList.get("linear solver : amg : sweeps", 2);
+    const int levels = mPList.get("linear solver : amg : max levels", 10);
+    const mx::YeeAssembler<double>& a = mSim->getAssembler();
+    mxg_ctx* ctx = mBMap->getComm()->getCtx();
+    if (mVecMg) mxh_mg_destroy(mVecMg);
+    mVecMg = mxh_mg_build(ctx, mShiftedVecLapl->getHostCsr(), a.bfield(), a.config().n, 2000, levels, sweeps, 30, 0.7, 1.9);
+    if (mHasCurlNull && !mScaMg)
+      mScaMg = mxh_mg_build(ctx, mScaLapl->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.7, 1.9);
   }
 
   int solve(mxg_ctx* ctx, mxg_csr* A, mxg_mv* b, mxg_mv* x, mxg_solve_info* info, mxh_mg* mg) const {

@@ -314,9 +314,6 @@ class MxProblem {
     if (!eigSet) getEigensolver(XMLNode());
     if (!gridSet) getGrid(XMLNode());
     if (!bcSet) getBCs(XMLNode());
-    if (pList.get("is complex", false))
-      throw std::runtime_error("MxProblem: non-zero phase shifts need the complex solver, which this build "
-                               "does not provide (real 3-D path only).");
     cfg.strict = mStrict;
     if (!comm.is_null()) sim = rcp(new MxEMSim<DIM>(cfg, comm, pList));
   }
@@ -324,9 +321,17 @@ class MxProblem {
   // reference main(): `prob3d = new MxProblem<3>(xmlObj, myComm); prob3d->solve();`
   void solve() {
     if (sim.is_null()) throw std::runtime_error("MxProblem::solve: parsed without a communicator");
-    solver = rcp(new MxSolver<DIM, double>(sim, pList));
-    solver->solve();
+    if (pList.get("is complex", false)) {       // src/MxProblem.cpp:160-175: MxSolver<DIM, MxComplex> when "is complex"
+      csolver = rcp(new MxSolver<DIM, MxComplex>(sim, pList));
+      csolver->solve();
+    } else {
+      solver = rcp(new MxSolver<DIM, double>(sim, pList));
+      solver->solve();
+    }
   }
+  bool isComplex() const { return pList.get("is complex", false); }
+  std::vector<MxComplex> const& frequencies() const { return isComplex() ? csolver->frequencies() : solver->frequencies(); }
+  std::vector<double> const& residuals() const { return isComplex() ? csolver->residuals() : solver->residuals(); }
 
   // MxSolver::solve writes the eigenvector files like the reference (src/MxSolver.cpp:222-224)
   void setSaveFields(bool on) { pList.set("io : save fields", on); }
@@ -335,6 +340,7 @@ class MxProblem {
   std::string const& getName() const { return mName; }
   RCP<MxEMSim<DIM> > getSim() const { return sim; }
   RCP<MxSolver<DIM, double> > getSolver() const { return solver; }
+  RCP<MxSolver<DIM, MxComplex> > getComplexSolver() const { return csolver; }
 
   // format: name, default, type  (src/MxProblem.cpp:20-66)
   static const char* const (*eigSolverParams())[3] {
@@ -561,6 +567,7 @@ class MxProblem {
   std::vector<std::shared_ptr<mx::Shape> > shapes;
   RCP<MxEMSim<DIM> > sim;
   RCP<MxSolver<DIM, double> > solver;
+  RCP<MxSolver<DIM, MxComplex> > csolver;
   bool gridSet, eigSet, bcSet;
   RCP<MxComm> comm;
   int pid;

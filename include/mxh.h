@@ -150,7 +150,12 @@ int mxh_problem_grid(mxh_problem* p, int n[3], double origin[3], double size[3],
                      int upper[3], double* dm_frac, int* has_pec);
 /* level-set value of the <PEC> shape at a point (MxShape::func, > 0 inside) */
 int mxh_problem_pec_func(mxh_problem* p, const double xyz[3], double* f);
-/* assemble (once) and return the simulation; owned by the problem */
+/* 1 if the deck needs complex arithmetic (non-zero Bloch phase shifts, src/MxProblem.cpp:640-642) */
+int mxh_problem_is_complex(mxh_problem* p);
+/* a named operator of the deck (as mxh_sim_op); for a complex deck `vals` are interleaved (re, im) pairs */
+int mxh_problem_op(mxh_problem* p, const char* name, int64_t* nrows, int64_t* ncols, int64_t* nnz,
+                   const int64_t** rowptr, const int32_t** colidx, const double** vals, int* is_complex);
+/* assemble (once) and return the simulation; owned by the problem (real decks only) */
 int mxh_problem_sim(mxh_problem* p, mxh_sim** sim);
 /* MxSolver with the deck's parameters on `ctx`; owned by the caller (mxh_solver_destroy) and
  * valid while the problem lives.  `verbose` < 0 keeps the deck's "output" level. */

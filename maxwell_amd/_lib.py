@@ -136,6 +136,9 @@ MXH_SIGNATURES = {
     "mxh_problem_grid": (C.c_int, [vp, C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), c_dp, c_ip]),
     "mxh_problem_pec_func": (C.c_int, [vp, c_dp, c_dp]),
+    "mxh_problem_is_complex": (C.c_int, [vp]),
+    "mxh_problem_op": (C.c_int, [vp, C.c_char_p, c_i64p, c_i64p, c_i64p, C.POINTER(c_i64p), C.POINTER(c_i32p),
+                                 C.POINTER(c_dp), c_ip]),
     "mxh_problem_sim": (C.c_int, [vp, C.POINTER(vp)]),
     "mxh_problem_solver": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
 }

@@ -515,6 +515,26 @@ class Problem:
         _chk(self.lib.mxh_problem_pec_func(self.h, p, C.byref(f)), self.lib, "mxh")
         return f.value
 
+    @property
+    def is_complex(self):
+        return bool(self.lib.mxh_problem_is_complex(self.h))
+
+    def op(self, name):
+        """scipy.sparse copy of a named operator; complex for decks with phase shifts."""
+        import scipy.sparse as sp
+        nr, nc, nz, cx = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        rp, ci, va = _lib.c_i64p(), _lib.c_i32p(), _lib.c_dp()
+        _chk(self.lib.mxh_problem_op(self.h, name.encode(), C.byref(nr), C.byref(nc), C.byref(nz), C.byref(rp),
+                                     C.byref(ci), C.byref(va), C.byref(cx)), self.lib, "mxh")
+        n = nz.value
+        rowptr = np.ctypeslib.as_array(rp, (nr.value + 1,)).copy()
+        col = np.ctypeslib.as_array(ci, (max(n, 1),))[:n].copy()
+        w = 2 if cx.value else 1
+        val = np.ctypeslib.as_array(va, (max(n * w, 1),))[:n * w].copy()
+        if cx.value:
+            val = val.view(np.complex128)
+        return sp.csr_matrix((val, col, rowptr), shape=(nr.value, nc.value))
+
     def sim(self):
         """The assembled simulation (owned by the problem; a Sim view that does not free it)."""
         if self._sim is None:
@@ -530,7 +550,7 @@ class Problem:
     def solver(self, ctx, verbose=0):
         h = C.c_void_p()
         _chk(self.lib.mxh_problem_solver(ctx.h, self.h, int(verbose), C.byref(h)), self.lib, "mxh")
-        s = Solver(ctx, self.sim(), _handle=h)
+        s = Solver(ctx, None if self.is_complex else self.sim(), _handle=h)
         s._owner = self
         return s
 

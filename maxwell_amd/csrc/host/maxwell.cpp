@@ -69,8 +69,8 @@ int main(int argc, char* argv[]) {
       if (eigFile != "") {
         std::ofstream out(eigFile.c_str());
         out << std::setprecision(17);
-        auto const& f = prob3d.getSolver()->frequencies();
-        auto const& e = prob3d.getSolver()->residuals();
+        auto const& f = prob3d.frequencies();
+        auto const& e = prob3d.residuals();
         for (size_t i = 0; i < f.size(); ++i) out << i << " " << f[i].real() << " " << f[i].imag() << " " << e[i] << "\n";
       }
     }   // solver, operators and vectors go before the context

@@ -10,6 +10,8 @@
 struct mxh_problem {
   std::unique_ptr<MxProblem<3> > prob;   // parsed without a communicator: no device needed
   std::unique_ptr<mxh_sim> sim;
+  // complex decks (Bloch phase shifts): operators assembled in complex arithmetic, exported interleaved
+  std::map<std::string, mx::Csr<std::complex<double> > > cops;
 };
 
 namespace {
@@ -92,8 +94,42 @@ extern "C" int mxh_problem_pec_func(mxh_problem* p, const double xyz[3], double*
   return 0;
 }
 
+extern "C" int mxh_problem_is_complex(mxh_problem* p) { return p->prob->isComplex() ? 1 : 0; }
+
+extern "C" int mxh_problem_op(mxh_problem* p, const char* name, int64_t* nrows, int64_t* ncols, int64_t* nnz,
+                              const int64_t** rowptr, const int32_t** colidx, const double** vals, int* is_complex) {
+  try {
+    if (!p->prob->isComplex()) {
+      mxh_sim* sim = nullptr;
+      if (mxh_problem_sim(p, &sim) != 0) return 1;
+      if (is_complex) *is_complex = 0;
+      return mxh_sim_op(sim, name, nrows, ncols, nnz, rowptr, colidx, vals);
+    }
+    if (p->cops.empty()) {
+      mx::YeeAssembler<std::complex<double> > a(p->prob->getConfig());
+      p->cops = a.waveOps();
+    }
+    auto it = p->cops.find(name);
+    if (it == p->cops.end()) throw std::runtime_error(std::string("MxEMOps::getOp: operator '") + name + "' not found.");
+    const mx::Csr<std::complex<double> >& m = it->second;
+    if (nrows) *nrows = m.nrows;
+    if (ncols) *ncols = m.ncols;
+    if (nnz) *nnz = m.nnz();
+    if (rowptr) *rowptr = m.rowptr.data();
+    if (colidx) *colidx = m.col.data();
+    if (vals) *vals = reinterpret_cast<const double*>(m.val.data());
+    if (is_complex) *is_complex = 1;
+    return 0;
+  } catch (const std::exception& e) {
+    mxh_set_error(e.what());
+    return 1;
+  }
+}
+
 extern "C" int mxh_problem_sim(mxh_problem* p, mxh_sim** out) {
   try {
+    if (p->prob->isComplex())
+      throw std::runtime_error("mxh_problem_sim: the deck is complex (phase shifts); use mxh_problem_op / mxh_problem_solver");
     if (!p->sim) {
       const auto t0 = std::chrono::steady_clock::now();
       std::unique_ptr<mxh_sim> s(new mxh_sim());
@@ -115,15 +151,19 @@ extern "C" int mxh_problem_sim(mxh_problem* p, mxh_sim** out) {
 extern "C" int mxh_problem_solver(mxg_ctx* ctx, mxh_problem* p, int verbose, mxh_solver** out) {
   try {
     if (!ctx || !p || !out) throw std::runtime_error("mxh_problem_solver: NULL argument");
-    mxh_sim* sim = nullptr;
-    if (mxh_problem_sim(p, &sim) != 0) return 1;
     Teuchos::ParameterList pl = p->prob->getParameters();
     if (verbose >= 0) pl.set("eigensolver : output", verbose);
     std::unique_ptr<mxh_solver> s(new mxh_solver());
     mxh_solver_default_params(&s->params);
     s->linType = pl.get("linear solver : type", "gmres");
     s->precType = pl.get("linear solver : prec type", "none");
-    mxh_solver_build(*s, ctx, sim, pl);
+    if (p->prob->isComplex()) {
+      mxh_solver_build_complex(*s, ctx, p->prob->getConfig(), pl);
+    } else {
+      mxh_sim* sim = nullptr;
+      if (mxh_problem_sim(p, &sim) != 0) return 1;
+      mxh_solver_build(*s, ctx, sim, pl);
+    }
     *out = s.release();
     return 0;
   } catch (const std::exception& e) {

@@ -1,4 +1,5 @@
 // C ABI over the eigen-driver (include/mxh.h, mxh_solver_*): MxSolver + MxMagWaveOp.
+#include <cstring>
 #include <memory>
 
 #include "mx/MxSolver.h"
@@ -18,6 +19,13 @@ void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::Parame
   s.params.shift = pl.get("eigensolver : shift", 0.0);
   s.sim = rcp(new MxEMSim<3>(sim->cfg, s.comm, pl, sim->asmb));
   s.solver.reset(new MxSolver<3, double>(s.sim, pl));
+}
+
+void mxh_solver_build_complex(mxh_solver& s, mxg_ctx* ctx, mx::YeeConfig const& cfg, Teuchos::ParameterList const& pl) {
+  s.comm = rcp(new MxComm(ctx));
+  s.params.shift = pl.get("eigensolver : shift", 0.0);
+  s.sim = rcp(new MxEMSim<3>(cfg, s.comm, pl));
+  s.csolver.reset(new MxSolver<3, MxComplex>(s.sim, pl));
 }
 
 extern "C" int mxh_solver_create(mxg_ctx* ctx, mxh_sim* sim, const mxh_solver_params* p, mxh_solver** out) {
@@ -61,6 +69,7 @@ extern "C" int mxh_solver_destroy(mxh_solver* s) {
 
 extern "C" int mxh_solver_solve(mxh_solver* s, int* nconv) {
   try {
+    if (s->csolver) { s->csolver->solve(); if (nconv) *nconv = (int)s->csolver->eigenvalues().size(); return 0; }
     s->solver->solve();
     if (nconv) *nconv = (int)s->solver->eigenvalues().size();
     return 0;
@@ -75,7 +84,7 @@ extern "C" int mxh_solver_solve(mxh_solver* s, int* nconv) {
 
 extern "C" int mxh_solver_result(mxh_solver* s, int i, double theta[2], double k2[2], double freq[2],
                                  double* residual, double* divergence) {
-  const auto& ev = s->solver->eigenvalues();
+  const auto& ev = s->csolver ? s->csolver->eigenvalues() : s->solver->eigenvalues();
   if (i < 0 || i >= (int)ev.size()) {
     mxh_set_error("mxh_solver_result: index out of range");
     return 1;
@@ -83,15 +92,26 @@ extern "C" int mxh_solver_result(mxh_solver* s, int i, double theta[2], double k
   const std::complex<double> kk = 1.0 / ev[i] + s->params.shift;   // src/MxMagWaveOp.cpp:1171-1179
   if (theta) { theta[0] = ev[i].real(); theta[1] = ev[i].imag(); }
   if (k2) { k2[0] = kk.real(); k2[1] = kk.imag(); }
-  if (freq) { freq[0] = s->solver->frequencies()[i].real(); freq[1] = s->solver->frequencies()[i].imag(); }
-  if (residual) *residual = s->solver->residuals()[i];
-  if (divergence) *divergence = s->solver->divergences()[i];
+  const auto& fr = s->csolver ? s->csolver->frequencies() : s->solver->frequencies();
+  if (freq) { freq[0] = fr[i].real(); freq[1] = fr[i].imag(); }
+  if (residual) *residual = s->csolver ? s->csolver->residuals()[i] : s->solver->residuals()[i];
+  if (divergence) *divergence = s->csolver ? s->csolver->divergences()[i] : s->solver->divergences()[i];
   return 0;
 }
 
 extern "C" int mxh_solver_stats(mxh_solver* s, int* num_applies, int* vec_lin_iters, int* sca_lin_iters,
                                 double* vec_solve_seconds, double* sca_solve_seconds,
                                 double* eigensolve_seconds) {
+  if (s->csolver) {
+    const auto& op = s->csolver->waveOp();
+    if (num_applies) *num_applies = op.numApplies();
+    if (vec_lin_iters) *vec_lin_iters = op.numVecLinIters();
+    if (sca_lin_iters) *sca_lin_iters = op.numScaLinIters();
+    if (vec_solve_seconds) *vec_solve_seconds = op.vecSolveTime();
+    if (sca_solve_seconds) *sca_solve_seconds = op.scaSolveTime();
+    if (eigensolve_seconds) *eigensolve_seconds = s->csolver->eigensolveSeconds();
+    return 0;
+  }
   const auto& op = s->solver->waveOp();
   if (num_applies) *num_applies = op.numApplies();
   if (vec_lin_iters) *vec_lin_iters = op.numVecLinIters();
@@ -104,6 +124,12 @@ extern "C" int mxh_solver_stats(mxh_solver* s, int* num_applies, int* vec_lin_it
 
 extern "C" int mxh_solver_eigvec(mxh_solver* s, int i, double* out) {
   try {
+    if (s->csolver) {     // complex: interleaved (re, im), 2 * rows doubles
+      std::vector<MxComplex> col;
+      s->csolver->magneticEigenvectors()->getColumn((size_t)i, col);
+      std::memcpy(out, col.data(), sizeof(MxComplex) * col.size());
+      return 0;
+    }
     std::vector<double> col;
     s->solver->magneticEigenvectors()->getColumn((size_t)i, col);
     std::copy(col.begin(), col.end(), out);

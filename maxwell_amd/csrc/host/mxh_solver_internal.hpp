@@ -12,12 +12,15 @@
 struct mxh_solver {
   RCP<MxComm> comm;
   RCP<MxEMSim<3> > sim;
-  std::unique_ptr<MxSolver<3, double> > solver;
+  std::unique_ptr<MxSolver<3, double> > solver;            // real problems
+  std::unique_ptr<MxSolver<3, MxComplex> > csolver;        // complex problems (Bloch phase shifts)
   mxh_solver_params params;
   std::string linType, precType;
 };
 
 // comm + MxEMSim (sharing the assembler of `sim`) + MxSolver from a complete parameter list
 void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::ParameterList const& pl);
+// complex problems (phase shifts): MxEMSim assembles in complex arithmetic itself
+void mxh_solver_build_complex(mxh_solver& s, mxg_ctx* ctx, mx::YeeConfig const& cfg, Teuchos::ParameterList const& pl);
 
 #endif

@@ -655,10 +655,11 @@ def mag_wave_modes(ops, shift, want, used=None):
         used = (M.diagonal() > 0) & (np.abs(ops["curlE"]).sum(axis=1).A1 > 0)
     idx = np.nonzero(used)[0]
     A = (L - shift * M)[np.ix_(idx, idx)]
-    T = np.zeros((n, n))
+    T = np.zeros((n, n), dtype=np.result_type(L.dtype, M.dtype))
     T[np.ix_(idx, idx)] = np.linalg.solve(A, M[np.ix_(idx, idx)])
     P = np.eye(n) + G @ np.linalg.pinv(S, rcond=1e-12) @ D @ M
     T = (P @ T)[np.ix_(idx, idx)]
     theta = np.linalg.eigvals(T)
     theta = theta[np.argsort(-np.abs(theta))][:want]
-    return np.sort((1.0 / theta + shift).real)
+    k2 = 1.0 / theta + shift
+    return k2[np.argsort(k2.real)].real if np.abs(k2.imag).max() <= 1e-9 * np.abs(k2).max() else k2[np.argsort(k2.real)]

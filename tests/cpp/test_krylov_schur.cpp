@@ -11,12 +11,13 @@
 
 typedef double S;
 
-class DenseMV : public Anasazi::MultiVec<S> {
+template <typename T>
+class DenseMVT : public Anasazi::MultiVec<T> {
  public:
-  DenseMV(int n, int k) : n_(n), k_(k), own_(new std::vector<double>((size_t)n * k, 0.0)), data_(own_.get()) { for (int j = 0; j < k; ++j) cols_.push_back(j); }
-  DenseMV(const DenseMV& o, const std::vector<int>& idx, bool copy) : n_(o.n_), k_((int)idx.size()) {
+  DenseMVT(int n, int k) : n_(n), k_(k), own_(new std::vector<T>((size_t)n * k, 0.0)), data_(own_.get()) { for (int j = 0; j < k; ++j) cols_.push_back(j); }
+  DenseMVT(const DenseMVT& o, const std::vector<int>& idx, bool copy) : n_(o.n_), k_((int)idx.size()) {
     if (copy) {
-      own_.reset(new std::vector<double>((size_t)n_ * k_));
+      own_.reset(new std::vector<T>((size_t)n_ * k_));
       data_ = own_.get();
       for (int j = 0; j < k_; ++j) { cols_.push_back(j); for (int i = 0; i < n_; ++i) at(i, j) = o.at(i, idx[j]); }
     } else {
@@ -24,51 +25,57 @@ class DenseMV : public Anasazi::MultiVec<S> {
       for (int j = 0; j < k_; ++j) cols_.push_back(o.cols_[idx[j]]);
     }
   }
-  double& at(int i, int j) { return (*data_)[(size_t)cols_[j] * n_ + i]; }
-  double at(int i, int j) const { return (*data_)[(size_t)cols_[j] * n_ + i]; }
-  Anasazi::MultiVec<S>* Clone(const int nv) const { return new DenseMV(n_, nv); }
-  Anasazi::MultiVec<S>* CloneCopy() const { std::vector<int> a(k_); for (int j = 0; j < k_; ++j) a[j] = j; return new DenseMV(*this, a, true); }
-  Anasazi::MultiVec<S>* CloneCopy(const std::vector<int>& idx) const { return new DenseMV(*this, idx, true); }
-  const Anasazi::MultiVec<S>* CloneView(const std::vector<int>& idx) const { return new DenseMV(*this, idx, false); }
-  Anasazi::MultiVec<S>* CloneViewNonConst(const std::vector<int>& idx) { return new DenseMV(*this, idx, false); }
+  T& at(int i, int j) { return (*data_)[(size_t)cols_[j] * n_ + i]; }
+  T at(int i, int j) const { return (*data_)[(size_t)cols_[j] * n_ + i]; }
+  Anasazi::MultiVec<T>* Clone(const int nv) const { return new DenseMVT(n_, nv); }
+  Anasazi::MultiVec<T>* CloneCopy() const { std::vector<int> a(k_); for (int j = 0; j < k_; ++j) a[j] = j; return new DenseMVT(*this, a, true); }
+  Anasazi::MultiVec<T>* CloneCopy(const std::vector<int>& idx) const { return new DenseMVT(*this, idx, true); }
+  const Anasazi::MultiVec<T>* CloneView(const std::vector<int>& idx) const { return new DenseMVT(*this, idx, false); }
+  Anasazi::MultiVec<T>* CloneViewNonConst(const std::vector<int>& idx) { return new DenseMVT(*this, idx, false); }
   int GetVecLength() const { return n_; }
   int GetNumberVecs() const { return k_; }
-  void MvTimesMatAddMv(S alpha, const Anasazi::MultiVec<S>& A_, const Teuchos::SerialDenseMatrix<int, S>& B, S beta) {
-    const DenseMV& A = dynamic_cast<const DenseMV&>(A_);
+  void MvTimesMatAddMv(T alpha, const Anasazi::MultiVec<T>& A_, const Teuchos::SerialDenseMatrix<int, T>& B, T beta) {
+    const DenseMVT& A = dynamic_cast<const DenseMVT<T>&>(A_);
     for (int j = 0; j < k_; ++j)
       for (int i = 0; i < n_; ++i) {
-        double s = 0; for (int l = 0; l < A.k_; ++l) s += A.at(i, l) * B(l, j);
-        at(i, j) = alpha * s + (beta == 0.0 ? 0.0 : beta * at(i, j));
+        T s = 0; for (int l = 0; l < A.k_; ++l) s += A.at(i, l) * B(l, j);
+        at(i, j) = alpha * s + (beta == T(0.0) ? T(0.0) : beta * at(i, j));
       }
   }
-  void MvAddMv(S a, const Anasazi::MultiVec<S>& A_, S b, const Anasazi::MultiVec<S>& B_) {
-    const DenseMV& A = dynamic_cast<const DenseMV&>(A_); const DenseMV& B = dynamic_cast<const DenseMV&>(B_);
+  void MvAddMv(T a, const Anasazi::MultiVec<T>& A_, T b, const Anasazi::MultiVec<T>& B_) {
+    const DenseMVT& A = dynamic_cast<const DenseMVT<T>&>(A_); const DenseMVT& B = dynamic_cast<const DenseMVT<T>&>(B_);
     for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) = a * A.at(i, j) + b * B.at(i, j);
   }
-  void MvTransMv(S alpha, const Anasazi::MultiVec<S>& A_, Teuchos::SerialDenseMatrix<int, S>& B) const {
-    const DenseMV& A = dynamic_cast<const DenseMV&>(A_);
-    for (int l = 0; l < A.k_; ++l) for (int j = 0; j < k_; ++j) { double s = 0; for (int i = 0; i < n_; ++i) s += A.at(i, l) * at(i, j); B(l, j) = alpha * s; }
+  void MvTransMv(T alpha, const Anasazi::MultiVec<T>& A_, Teuchos::SerialDenseMatrix<int, T>& B) const {
+    const DenseMVT& A = dynamic_cast<const DenseMVT<T>&>(A_);
+    for (int l = 0; l < A.k_; ++l) for (int j = 0; j < k_; ++j) { T s = 0; for (int i = 0; i < n_; ++i) s += cj(A.at(i, l)) * at(i, j); B(l, j) = alpha * s; }
   }
-  void MvDot(const Anasazi::MultiVec<S>& A_, std::vector<S>& b) const {
-    const DenseMV& A = dynamic_cast<const DenseMV&>(A_); b.resize(k_);
-    for (int j = 0; j < k_; ++j) { double s = 0; for (int i = 0; i < n_; ++i) s += A.at(i, j) * at(i, j); b[j] = s; }
+  void MvDot(const Anasazi::MultiVec<T>& A_, std::vector<T>& b) const {
+    const DenseMVT& A = dynamic_cast<const DenseMVT<T>&>(A_); b.resize(k_);
+    for (int j = 0; j < k_; ++j) { T s = 0; for (int i = 0; i < n_; ++i) s += cj(A.at(i, j)) * at(i, j); b[j] = s; }
   }
-  void MvNorm(std::vector<double>& nv) const { nv.resize(k_); for (int j = 0; j < k_; ++j) { double s = 0; for (int i = 0; i < n_; ++i) s += at(i, j) * at(i, j); nv[j] = std::sqrt(s); } }
-  void SetBlock(const Anasazi::MultiVec<S>& A_, const std::vector<int>& idx) {
-    const DenseMV& A = dynamic_cast<const DenseMV&>(A_);
+  void MvNorm(std::vector<double>& nv) const { nv.resize(k_); for (int j = 0; j < k_; ++j) { double s = 0; for (int i = 0; i < n_; ++i) s += std::norm(at(i, j)); nv[j] = std::sqrt(s); } }
+  void SetBlock(const Anasazi::MultiVec<T>& A_, const std::vector<int>& idx) {
+    const DenseMVT& A = dynamic_cast<const DenseMVT<T>&>(A_);
     for (size_t j = 0; j < idx.size() && (int)j < A.k_; ++j) for (int i = 0; i < n_; ++i) at(i, idx[j]) = A.at(i, (int)j);
   }
-  void MvScale(S a) { for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) *= a; }
-  void MvScale(const std::vector<S>& a) { for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) *= a[j]; }
-  void MvRandom() { static std::mt19937 g(7); std::uniform_real_distribution<double> u(-1, 1); for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) = u(g); }
-  void MvInit(S a) { for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) = a; }
+  void MvScale(T a) { for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) *= a; }
+  void MvScale(const std::vector<T>& a) { for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) *= a[j]; }
+  void MvRandom() { static std::mt19937 g(7); std::uniform_real_distribution<double> u(-1, 1); for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) = rnd(u, g, (T*)0); }
+  void MvInit(T a) { for (int j = 0; j < k_; ++j) for (int i = 0; i < n_; ++i) at(i, j) = a; }
   void MvPrint(std::ostream&) const {}
  private:
+  static double cj(double v) { return v; }
+  static std::complex<double> cj(std::complex<double> v) { return std::conj(v); }
+  template <typename U, typename G> static double rnd(U& u, G& g, double*) { return u(g); }
+  template <typename U, typename G> static std::complex<double> rnd(U& u, G& g, std::complex<double>*) { double a = u(g), b = u(g); return std::complex<double>(a, b); }
   int n_, k_;
-  std::shared_ptr<std::vector<double> > own_;
-  std::vector<double>* data_;
+  std::shared_ptr<std::vector<T> > own_;
+  std::vector<T>* data_;
   std::vector<int> cols_;
 };
+
+typedef DenseMVT<S> DenseMV;
 
 struct DiagOp : Anasazi::Operator<S> {
   std::vector<double> d;
@@ -240,17 +247,61 @@ int main() {
     CHECK(std::fabs(sol.Evals[1].realpart - 2.0) < 1e-8 && std::fabs(sol.Evals[1].imagpart + 1.5) < 1e-8 && sol.index[1] == -1);
     CHECK(std::fabs(sol.Evals[2].realpart - 2.0) < 1e-8 && sol.Evals[2].imagpart == 0.0);
   }
-  {  // 5d. complex scalars + non-Hermitian are refused loudly (not built)
+  {  // 5d. complex scalars: Hermitian operator U D U^H (U = diagonal phases times a Householder reflector) and a
+     //     non-Hermitian one (complex diagonal + upper part); both through the complex path
     typedef std::complex<double> Z;
-    struct NoOp : Anasazi::Operator<Z> { void Apply(const Anasazi::MultiVec<Z>&, Anasazi::MultiVec<Z>&) const {} };
-    RCP<Anasazi::Operator<Z> > op(new NoOp());
-    RCP<Anasazi::MultiVec<Z> > init;   // never dereferenced: the constructor checks come first
-    RCP<Anasazi::BasicEigenproblem<Z, Anasazi::MultiVec<Z>, Anasazi::Operator<Z> > > prob(
-        new Anasazi::BasicEigenproblem<Z, Anasazi::MultiVec<Z>, Anasazi::Operator<Z> >(op, init));
-    Teuchos::ParameterList pl;
-    bool threw = false;
-    try { Anasazi::BlockKrylovSchurSolMgr<Z, Anasazi::MultiVec<Z>, Anasazi::Operator<Z> > mgr(prob, pl); } catch (const std::invalid_argument&) { threw = true; }
-    CHECK(threw);
+    typedef Anasazi::MultiVec<Z> ZMV;
+    typedef Anasazi::Operator<Z> ZOP;
+    const int n = 200;
+    struct HermOp : ZOP {
+      std::vector<double> d; std::vector<Z> u;
+      void Apply(const ZMV& x_, ZMV& y_) const {
+        const DenseMVT<Z>& x = dynamic_cast<const DenseMVT<Z>&>(x_); DenseMVT<Z>& y = dynamic_cast<DenseMVT<Z>&>(y_);
+        const int nn = x.GetVecLength();
+        std::vector<Z> t(nn);
+        for (int j = 0; j < x.GetNumberVecs(); ++j) {
+          Z s(0.0);                                  // t = (I - 2 u u^H) x
+          for (int i = 0; i < nn; ++i) s += std::conj(u[i]) * x.at(i, j);
+          for (int i = 0; i < nn; ++i) t[i] = d[i] * (x.at(i, j) - 2.0 * u[i] * s);
+          s = Z(0.0);
+          for (int i = 0; i < nn; ++i) s += std::conj(u[i]) * t[i];
+          for (int i = 0; i < nn; ++i) y.at(i, j) = t[i] - 2.0 * u[i] * s;
+        }
+      }
+    };
+    RCP<HermOp> hop(new HermOp());
+    double un = 0;
+    for (int i = 0; i < n; ++i) { hop->d.push_back(1.0 / (1.0 + 0.5 * i)); hop->u.push_back(Z(std::cos(0.3 * i), std::sin(0.7 * i))); un += std::norm(hop->u.back()); }
+    for (auto& v : hop->u) v /= std::sqrt(un);
+    struct TriOpZ : ZOP {
+      std::vector<Z> d;
+      void Apply(const ZMV& x_, ZMV& y_) const {
+        const DenseMVT<Z>& x = dynamic_cast<const DenseMVT<Z>&>(x_); DenseMVT<Z>& y = dynamic_cast<DenseMVT<Z>&>(y_);
+        const int nn = x.GetVecLength();
+        for (int j = 0; j < x.GetNumberVecs(); ++j)
+          for (int i = 0; i < nn; ++i) y.at(i, j) = d[i] * x.at(i, j) + (i + 1 < nn ? Z(0.03, 0.02) * x.at(i + 1, j) : Z(0.0));
+      }
+    };
+    RCP<TriOpZ> top(new TriOpZ());
+    for (int i = 0; i < n; ++i) top->d.push_back(Z(1.0 / (1.0 + 0.6 * i), 0.2 / (1.0 + i)));
+    for (int which = 0; which < 2; ++which) {
+      RCP<ZMV> init(new DenseMVT<Z>(n, 1)); init->MvRandom();
+      RCP<ZOP> op = which == 0 ? RCP<ZOP>(hop) : RCP<ZOP>(top);
+      RCP<Anasazi::BasicEigenproblem<Z, ZMV, ZOP> > prob(new Anasazi::BasicEigenproblem<Z, ZMV, ZOP>(op, init));
+      prob->setNEV(3); prob->setHermitian(which == 0);
+      CHECK(prob->setProblem());
+      Teuchos::ParameterList pl;
+      pl.set("Which", "LM"); pl.set("Block Size", 1); pl.set("Num Blocks", 14); pl.set("Maximum Restarts", 300);
+      pl.set("Convergence Tolerance", 1e-10); pl.set("Verbosity", 0);
+      Anasazi::BlockKrylovSchurSolMgr<Z, ZMV, ZOP> mgr(prob, pl);
+      CHECK(mgr.solve() == Anasazi::Converged);
+      const Anasazi::Eigensolution<Z, ZMV>& sol = prob->getSolution();
+      CHECK(sol.numVecs >= 3);
+      for (int i = 0; i < 3 && i < sol.numVecs; ++i) {
+        const Z want = which == 0 ? Z(1.0 / (1.0 + 0.5 * i), 0.0) : top->d[i];
+        CHECK(std::abs(Z(sol.Evals[i].realpart, sol.Evals[i].imagpart) - want) < 1e-8);
+      }
+    }
   }
   {  // 6. the small symmetric eigen-solver
     const int n = 5;

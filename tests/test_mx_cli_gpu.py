@@ -159,3 +159,34 @@ def test_dielectric_sphere_deck_non_hermitian(ctx):
     k = np.sqrt(k2)
     assert abs(k[0] - 2.7914257502896397024) / 2.7914 < 5e-3       # TM_11, O(h^2) at resolution 12
     assert abs(k[1] - 4.0593020005144315490) / 4.0593 < 1e-2       # TE_21
+
+
+def test_complex_decks_bloch_phase_shifts(ctx):
+    """Complex arithmetic end to end (src/MxProblem.cpp:160-175: MxSolver<DIM, MxComplex> when "is complex"):
+    complex assembler -> complex CSR / multivectors -> complex GMRES -> complex Krylov-Schur.
+    (a) periodic vacuum with Bloch phases: the exact spectrum sum_i (2/h_i sin((pi m_i + phi_i/2)/N_i))^2;
+    (b) the dielectric-fibre deck in the manner of example/cylinder.py against the oracle's dense restatement.
+    Both with strict=False: the reference's periodic-wrap quirk makes a periodic
+    operator non-self-adjoint and its spectrum complex."""
+    text = open(os.path.join(GOLDEN, "vacuum.mx")).read().replace("phase shifts = [0.0, 0.0, 0.0]", "phase shifts = [0.7, 0.0, -0.4]")
+    text = text.replace('<LinearSolver type="cg">', '<LinearSolver type="gmres">').replace('<Preconditioner type="amg"/>', '<Preconditioner type="ilu"/>')
+    deck = mxdeck.Deck(text)
+    prob = mx.Problem(text=text, strict=False)
+    assert prob.is_complex
+    solver = prob.solver(ctx)
+    assert solver.solve() == 5
+    res = [solver.result(i) for i in range(5)]
+    k2 = np.sort([r["k2"].real for r in res])
+    n, h, ph = np.array(deck.n), np.array(deck.size) / np.array(deck.n), np.array(deck.phase)
+    exact = np.sort([float(np.sum((2.0 / h * np.sin((np.pi * np.array(m) + ph / 2) / n)) ** 2)) for m in np.ndindex(*n)] * 2)[:5]
+    assert np.abs(k2 - exact).max() / exact.max() < 50 * deck.params["eigensolver : tol"], (k2, exact)
+    assert max(abs(r["k2"].imag) for r in res) < 1e-6 * exact.max()
+
+    name = os.path.join(GOLDEN, "fiber.mx")
+    deck = mxdeck.load(name)
+    solver = mx.Problem(path=name, strict=False).solver(ctx)
+    assert solver.solve() == 4
+    k2 = np.sort([solver.result(i)["k2"].real for i in range(4)])
+    want = yee.mag_wave_modes(deck.sim(strict=False).wave_ops(), deck.params["eigensolver : shift"], 4)
+    assert np.isrealobj(want)
+    assert np.abs(k2 - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (k2, want)

@@ -15,6 +15,7 @@ from oracle import mxdeck
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 pytestmark = pytest.mark.usefixtures("built")
 DECKS = ["pillbox.mx", "vacuum.mx", "tilted_cavity.mx", "dsphmsph.mx"]
+COMPLEX_DECKS = ["fiber.mx"]
 
 
 def _text(name):
@@ -83,8 +84,6 @@ def test_body_line_wins_over_tag_attribute():
     ("<S>\n polarization = TE\n <PEC>\n <Torus>\n name = t\n </Torus>\n </PEC>\n</S>", "Torus"),
     ("<S>\n polarization = TE\n <Eigensolver>\n <LinearSolver>\n <Preconditioner>\n type = foo\n </Preconditioner>\n"
      " </LinearSolver>\n </Eigensolver>\n</S>", "Preconditioner type"),
-    ("<S>\n polarization = TE\n <BoundaryConditions>\n phase shifts = [0.1, 0, 0]\n </BoundaryConditions>\n</S>",
-     "phase shifts"),
     ("<S>\n polarization = TE\n <Grid>\n</S>", "parse error"),
     ("<S>\n polarization = TE\n", "parse error"),
 ])
@@ -137,3 +136,21 @@ def test_dm_frac_zeroes_small_faces():
     rows_b = np.abs(cb).sum(axis=1).A1 > 0
     assert rows_b.sum() < (np.abs(ca).sum(axis=1).A1 > 0).sum()
     assert not (rows_b & ~rows_a).any()
+
+
+@pytest.mark.parametrize("name", COMPLEX_DECKS)
+def test_complex_deck_operators_bit_identical(name):
+    """Bloch phase shifts: the complex assembler (YeeAssembler<complex>) against the complex oracle, incl. the FIT
+    inverse permittivity and a two-cell periodic direction (repeated (row, col) entries are summed)."""
+    deck = mxdeck.Deck(_text(name))
+    assert deck.params["is complex"]
+    prob = mx.Problem(text=_text(name))
+    assert prob.is_complex and prob.param("is complex") == "1"
+    with pytest.raises(mx.MxError, match="complex"):
+        prob.sim()
+    ops = deck.sim().wave_ops()
+    for opname, ref in ops.items():
+        a, b = prob.op(opname).tocsr(), ref.tocsr()
+        assert np.iscomplexobj(a.data) and a.shape == b.shape
+        d = a - b
+        assert d.nnz == 0 or np.abs(d.data).max() == 0.0, opname
