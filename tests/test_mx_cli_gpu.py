@@ -170,7 +170,9 @@ def test_complex_decks_bloch_phase_shifts(ctx):
     operator non-self-adjoint and its spectrum complex."""
     text = open(os.path.join(GOLDEN, "vacuum.mx")).read().replace("phase shifts = [0.0, 0.0, 0.0]", "phase shifts = [0.7, 0.0, -0.4]")
     text = text.replace('<LinearSolver type="cg">', '<LinearSolver type="gmres">').replace('<Preconditioner type="amg"/>', '<Preconditioner type="ilu"/>')
+    text = text.replace("tol = 1.0e-8\n    shift", "tol = 1.0e-8\n    block size = 2\n    shift")   # every level is a polarisation pair
     deck = mxdeck.Deck(text)
+    assert deck.params["eigensolver : block size"] == 2
     prob = mx.Problem(text=text, strict=False)
     assert prob.is_complex
     solver = prob.solver(ctx)
