@@ -58,13 +58,14 @@ class MxGridField {
 template <size_t DIM>
 class MxEMSim {
  public:
-  // A problem with Bloch phase shifts is assembled in complex arithmetic (src/MxGridField.cpp:34-38,157-188);
+  // A problem with Bloch phase shifts (src/MxGridField.cpp:34-38,157-188) or lossy dielectrics is assembled in complex arithmetic;
   // everything else in real arithmetic.
   MxEMSim(mx::YeeConfig const& cfg, RCP<MxComm> comm, Teuchos::ParameterList pList = Teuchos::ParameterList(),
           std::shared_ptr<mx::YeeAssembler<double> > assembler = nullptr)
       : mCfg(cfg), mGrid(comm), mPList(pList) {
     static_assert(DIM == 3, "only the 3-D path is built");
     mComplex = cfg.phaseShifts[0] != 0.0 || cfg.phaseShifts[1] != 0.0 || cfg.phaseShifts[2] != 0.0;
+    for (auto const& dl : cfg.dielectrics) if (dl.lossy()) mComplex = true;   // loss tangent, src/MxProblem.cpp:507-508
     if (mComplex) {
       mAsmC = std::make_shared<mx::YeeAssembler<MxComplex> >(cfg);
       addFields(*mAsmC, comm);

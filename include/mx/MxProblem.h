@@ -6,7 +6,8 @@
 //
 // In scope: 3-D, Grid, BoundaryConditions, PEC and lossless Dielectric blocks with
 // Cylinder / Sphere / Slab / HalfSpace / ShapeIntersection and the generic transforms, Eigensolver /
-// LinearSolver / Preconditioner.  Mu / PML blocks, loss tangents and the remaining shape tags are
+// LinearSolver / Preconditioner (phase shifts and loss tangents select the complex solver).  Mu / PML
+// blocks and the remaining shape tags are
 // rejected with a message instead of being ignored (a wrong answer would be silent otherwise).
 //
 // Deviation: the reference runs the solve inside the constructor and leaves solve() empty
@@ -531,11 +532,10 @@ class MxProblem {
     double diag[3], off[3];
     mxdetail::strFill(getAttr("eps diag", node, "[1.0, 1.0, 1.0]"), diag, 3, 0.0);
     mxdetail::strFill(getAttr("eps off diag", node, "[0.0, 0.0, 0.0]"), off, 3, 0.0);
-    if (atof(getAttr("loss tangent", node, "0.0").c_str()) != 0.0)
-      throw std::runtime_error("MxProblem: <Dielectric> '" + d.name + "' has a loss tangent: complex permittivity "
-                               "needs the complex solver, which this build does not provide.");
+    const double losstan = atof(getAttr("loss tangent", node, "0.0").c_str());
+    if (losstan != 0) pList.set("is complex", true);                         // src/MxProblem.cpp:507-508
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d.eps[i][j] = 0.0;
-    for (int i = 0; i < 3; ++i) d.eps[i][i] = diag[i];
+    for (int i = 0; i < 3; ++i) { d.eps[i][i] = diag[i]; d.epsIm[i][i] = diag[i] * losstan; }   // :511-513
     d.eps[0][1] = d.eps[1][0] = off[2];
     d.eps[0][2] = d.eps[2][0] = off[1];
     d.eps[1][2] = d.eps[2][1] = off[0];

@@ -278,8 +278,9 @@ class Sim:
 
     def __init__(self, n, origin=(0.0, 0.0, 0.0), size=(1.0, 1.0, 1.0), lower=("periodic",) * 3,
                  upper=("periodic",) * 3, pec_shape=None, strict=True, dielectrics=None, dm_frac=0.0):
-        """dielectrics: list of (eps, shape_spec); eps = 3 diagonal numbers, or 6 (diag + the deck's
-        `eps off diag` triple), or a scalar for an isotropic material."""
+        """dielectrics: list of (eps, shape_spec[, loss_tangent]); eps = 3 diagonal numbers, or 6 (diag + the
+        deck's `eps off diag` triple), or a scalar for an isotropic material.  A loss tangent makes the problem
+        complex: its operators come from Problem.op, not from Sim."""
         self.lib = _lib.load_mxhost()
         n = [int(n)] * 3 if np.ndim(n) == 0 else [int(v) for v in n]
         self.n = n
@@ -292,9 +293,11 @@ class Sim:
         dspec = None
         if dielectrics:
             items = []
-            for eps, shape in dielectrics:
+            for item in dielectrics:
+                eps, shape = item[0], item[1]
+                tan = float(item[2]) if len(item) > 2 else 0.0
                 e = [float(eps)] * 3 if np.ndim(eps) == 0 else [float(v) for v in eps]
-                items.append(",".join(repr(v) for v in e) + " : " + shape)
+                items.append(",".join(repr(v) for v in e) + (" tan=%r" % tan if tan else "") + " : " + shape)
             dspec = " | ".join(items).encode()
         _chk(self.lib.mxh_sim_create_ex(nn, oo, ss, lo, up, pec_shape.encode() if pec_shape else None, dspec,
                                         float(dm_frac), int(bool(strict)), None, None, C.byref(h)), self.lib, "mxh")

@@ -40,8 +40,10 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
     phase_[i] = std::exp(std::complex<double>(0.0, 1.0) * cfg.phaseShifts[i]);  // src/MxGridField.cpp:34-38
     if (cfg.phaseShifts[i] != 0.0) complexProblem_ = true;
   }
+  for (const YeeDielectric& dl : cfg.dielectrics) if (dl.lossy()) lossy_ = true;
+  if (lossy_) complexProblem_ = true;
   if (complexProblem_ && sizeof(S) == sizeof(double))
-    throw std::runtime_error("phase shifts need the complex assembler");
+    throw std::runtime_error("phase shifts / lossy dielectrics need the complex assembler");
   B_.name = "bfield"; E_.name = "efield"; P_.name = "psifield"; D_.name = "dfield";
   B_.ncomp = 3; E_.ncomp = 3; P_.ncomp = 1; D_.ncomp = 3;
   for (int c = 0; c < 3; ++c)
@@ -547,6 +549,90 @@ void YeeAssembler<S>::tupleUpdate(const int comps[3], const int cells[3][3], con
   matmul3(aveG, inv, out);
 }
 
+namespace {
+
+typedef std::complex<double> Cx;
+// explicit complex arithmetic (naive product and quotient), mirrored operation by operation in oracle/yee.py
+inline Cx cmul(const Cx& a, const Cx& b) { return Cx(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real()); }
+inline Cx cdiv(const Cx& a, const Cx& b) {
+  const double den = b.real() * b.real() + b.imag() * b.imag();
+  return Cx((a.real() * b.real() + a.imag() * b.imag()) / den, (a.imag() * b.real() - a.real() * b.imag()) / den);
+}
+void matmul3c(const Cx x[3][3], const Cx y[3][3], Cx out[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Cx acc(0.0, 0.0);
+      for (int k = 0; k < 3; ++k) acc = acc + cmul(x[i][k], y[k][j]);
+      out[i][j] = acc;
+    }
+}
+void inverse3c(const Cx a[3][3], Cx r[3][3]) {
+  const Cx det = cmul(a[0][0], cmul(a[1][1], a[2][2]) - cmul(a[1][2], a[2][1])) -
+                 cmul(a[0][1], cmul(a[1][0], a[2][2]) - cmul(a[1][2], a[2][0])) +
+                 cmul(a[0][2], cmul(a[1][0], a[2][1]) - cmul(a[1][1], a[2][0]));
+  r[0][0] = cdiv(cmul(a[1][1], a[2][2]) - cmul(a[1][2], a[2][1]), det);
+  r[0][1] = cdiv(cmul(a[0][2], a[2][1]) - cmul(a[0][1], a[2][2]), det);
+  r[0][2] = cdiv(cmul(a[0][1], a[1][2]) - cmul(a[0][2], a[1][1]), det);
+  r[1][0] = cdiv(cmul(a[1][2], a[2][0]) - cmul(a[1][0], a[2][2]), det);
+  r[1][1] = cdiv(cmul(a[0][0], a[2][2]) - cmul(a[0][2], a[2][0]), det);
+  r[1][2] = cdiv(cmul(a[0][2], a[1][0]) - cmul(a[0][0], a[1][2]), det);
+  r[2][0] = cdiv(cmul(a[1][0], a[2][1]) - cmul(a[1][1], a[2][0]), det);
+  r[2][1] = cdiv(cmul(a[0][1], a[2][0]) - cmul(a[0][0], a[2][1]), det);
+  r[2][2] = cdiv(cmul(a[0][0], a[1][1]) - cmul(a[0][1], a[1][0]), det);
+}
+void gammaPiC(const Cx eps[3][3], const double n[3], Cx gamma[3][3], Cx pi[3][3]) {
+  Cx nc[3] = {Cx(n[0], 0.0), Cx(n[1], 0.0), Cx(n[2], 0.0)}, epsn[3], ime[3][3], nn[3][3], prod[3][3];
+  for (int i = 0; i < 3; ++i) epsn[i] = cmul(eps[i][0], nc[0]) + cmul(eps[i][1], nc[1]) + cmul(eps[i][2], nc[2]);
+  const Cx denom = cmul(nc[0], epsn[0]) + cmul(nc[1], epsn[1]) + cmul(nc[2], epsn[2]);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { ime[i][j] = Cx(i == j ? 1.0 : 0.0, 0.0) - eps[i][j]; nn[i][j] = cmul(nc[i], nc[j]); }
+  matmul3c(nn, ime, prod);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) gamma[i][j] = Cx(i == j ? 1.0 : 0.0, 0.0) + cdiv(prod[i][j], denom);
+  matmul3c(eps, gamma, pi);
+}
+
+}  // namespace
+
+// tupleUpdate for complex permittivity (loss tangent)
+template <typename S>
+void YeeAssembler<S>::tupleUpdateC(const int comps[3], const int cells[3][3], const double n[3], Cx out[3][3]) const {
+  Cx aveG[3][3], aveP[3][3], gamma[3][3], pi[3][3];
+  for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) { aveG[j][k] = Cx(0.0, 0.0); aveP[j][k] = Cx(0.0, 0.0); }
+  double lsum[3] = {0, 0, 0}, asum[3] = {0, 0, 0};
+  for (size_t i = 0; i < cfg_.dielectrics.size(); ++i) {
+    double lf[3] = {0, 0, 0}, af[3] = {0, 0, 0};
+    for (int j = 0; j < 3; ++j) {
+      const int c = comps[j];
+      lf[c] = dielFracAt(E_, i, c, cells[j]);
+      af[c] = dielFracAt(D_, i, c, cells[j]);
+      lsum[c] += lf[c];
+      asum[c] += af[c];
+    }
+    Cx eps[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) eps[a][b] = Cx(cfg_.dielectrics[i].eps[a][b], cfg_.dielectrics[i].epsIm[a][b]);
+    gammaPiC(eps, n, gamma, pi);
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) {
+        aveG[j][k] = aveG[j][k] + cmul(Cx(lf[j], 0.0), gamma[j][k]);
+        aveP[j][k] = aveP[j][k] + cmul(Cx(af[j], 0.0), pi[j][k]);
+      }
+  }
+  Cx bg[3][3];
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) bg[a][b] = Cx(a == b ? 1.0 : 0.0, 0.0);
+  gammaPiC(bg, n, gamma, pi);
+  for (int j = 0; j < 3; ++j) {
+    const double lfj = 1.0 - lsum[j], afj = 1.0 - asum[j];
+    for (int k = 0; k < 3; ++k) {
+      aveG[j][k] = aveG[j][k] + cmul(Cx(lfj, 0.0), gamma[j][k]);
+      aveP[j][k] = aveP[j][k] + cmul(Cx(afj, 0.0), pi[j][k]);
+    }
+  }
+  Cx inv[3][3];
+  inverse3c(aveP, inv);
+  matmul3c(aveG, inv, out);
+}
+
 // getNormal, src/MxYeeFitInvEps.cpp:254-302
 template <typename S>
 void YeeAssembler<S>::stencilNormal(int comp0, const int cell[3], const int scomps[9], const int scells[9][3],
@@ -596,14 +682,14 @@ Csr<S> YeeAssembler<S>::invEps() const {
     winCell(E_.wcell[r], ucell);
     canon(ucell, cell);
     bool inDiel = false, epsDiag = false;
-    double epsHere = 1.0;
+    std::complex<double> epsHere(1.0, 0.0);
     for (size_t i = 0; i < nd; ++i) {                                        // :462-479
       const double l0 = dielFracAt(E_, i, comp0, cell), a0 = dielFracAt(D_, i, comp0, cell);
       const double (*e)[3] = cfg_.dielectrics[i].eps;
       if (l0 == 1 && a0 == 1) {
         inDiel = true;
         epsDiag = !(std::abs(e[0][1]) > 0.0 || std::abs(e[0][2]) > 0.0 || std::abs(e[1][2]) > 0.0);   // checkIsDiag, dEps = 0
-        epsHere = e[comp0][comp0];
+        epsHere = std::complex<double>(e[comp0][comp0], cfg_.dielectrics[i].epsIm[comp0][comp0]);
         break;
       } else if (l0 == 0 && a0 == 0) {
         continue;
@@ -612,13 +698,13 @@ Csr<S> YeeAssembler<S>::invEps() const {
         break;
       }
     }
-    if (!inDiel) { epsDiag = true; epsHere = 1.0; }
+    if (!inDiel) { epsDiag = true; epsHere = std::complex<double>(1.0, 0.0); }
     int32_t* rc = cols.data() + r * 9;
     S* rv = vals.data() + r * 9;
     if (epsDiag) {                                                           // :505-512
       const std::complex<double> fac = factor(D_, comp0, cell);
       rc[0] = (int32_t)r;
-      rv[0] = toScalar(fac / epsHere);
+      rv[0] = toScalar(lossy_ ? cdiv(fac, epsHere) : fac / epsHere.real());
       cnt[r] = 1;
       continue;
     }
@@ -645,14 +731,21 @@ Csr<S> YeeAssembler<S>::invEps() const {
       if (ok) use[nt++] = t;
     }
     double svals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::complex<double> svalsC[9];
     const double ntd = double(nt);
     for (int u = 0; u < nt; ++u) {                                            // :519-531
       const int* t = tupleInds[use[u]];
       int tcomps[3], tcells[3][3];
       for (int j = 0; j < 3; ++j) { tcomps[j] = scomps[t[j]]; for (int a = 0; a < 3; ++a) tcells[j][a] = scells[t[j]][a]; }
-      double m[3][3];
-      tupleUpdate(tcomps, tcells, normal, m);
-      for (int j = 0; j < 3; ++j) svals[t[j]] += m[comp0][scomps[t[j]]] / ntd;
+      if (lossy_) {
+        std::complex<double> m[3][3];
+        tupleUpdateC(tcomps, tcells, normal, m);
+        for (int j = 0; j < 3; ++j) svalsC[t[j]] = svalsC[t[j]] + m[comp0][scomps[t[j]]] / ntd;
+      } else {
+        double m[3][3];
+        tupleUpdate(tcomps, tcells, normal, m);
+        for (int j = 0; j < 3; ++j) svals[t[j]] += m[comp0][scomps[t[j]]] / ntd;
+      }
     }
     int n = 0;
     for (int s = 0; s < 9; ++s) {                                             // :533-537
@@ -662,7 +755,7 @@ Csr<S> YeeAssembler<S>::invEps() const {
       const int32_t lid = lidOf(D_, scomps[s], ic);
       if (lid < 0) continue;
       rc[n] = lid;
-      rv[n] = S(svals[s]) * toScalar(fac);
+      rv[n] = lossy_ ? toScalar(cmul(svalsC[s], fac)) : S(svals[s]) * toScalar(fac);
       ++n;
     }
     // sort by column, merge repeated columns in insertion order (Epetra FillComplete)
@@ -702,6 +795,20 @@ Csr<S> YeeAssembler<S>::invEpsVolAve() const {
     int ucell[3], cell[3];
     winCell(P_.wcell[r], ucell);
     canon(ucell, cell);
+    if (lossy_) {
+      std::complex<double> acc(0.0, 0.0);
+      double sums = 0.0;
+      for (size_t i = 0; i < cfg_.dielectrics.size(); ++i) {
+        const YeeDielectric& dl = cfg_.dielectrics[i];
+        const std::complex<double> tr = std::complex<double>(dl.eps[0][0], dl.epsIm[0][0]) + std::complex<double>(dl.eps[1][1], dl.epsIm[1][1]) +
+                                        std::complex<double>(dl.eps[2][2], dl.epsIm[2][2]);
+        const double fr = dielFracAt(P_, i, 0, cell);
+        sums = sums + fr;
+        acc = acc + cmul(std::complex<double>(fr, 0.0), cdiv(std::complex<double>(3.0, 0.0), tr));
+      }
+      d[r] = toScalar(acc + std::complex<double>((1.0 - sums) * (3.0 / 3.0), 0.0));
+      continue;
+    }
     double out = 0.0, sums = 0.0;
     for (size_t i = 0; i < cfg_.dielectrics.size(); ++i) {
       const double (*e)[3] = cfg_.dielectrics[i].eps;

@@ -33,12 +33,17 @@ namespace mx {
 enum BcKind { BC_PERIODIC = 0, BC_PEC = 1, BC_PMC = 2 };          // user-level (MxTypes.h)
 enum CompBc { CBC_PERIODIC = 0, CBC_ZERO = 1, CBC_CONSTANT = 2 };  // per component and axis
 
-// <Dielectric> block (src/MxProblem.cpp:487-527, src/MxDielectric.cpp): real symmetric tensor only
-// (a loss tangent makes eps complex; not built)
+// <Dielectric> block (src/MxProblem.cpp:487-527, src/MxDielectric.cpp): symmetric tensor; a loss tangent
+// t makes the diagonal complex, eps_ii (1 + i t) (src/MxProblem.cpp:505-513) and the problem complex
 struct YeeDielectric {
   std::string name;
   std::shared_ptr<const Shape> shape;
   double eps[3][3];
+  double epsIm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  bool lossy() const {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (epsIm[i][j] != 0.0) return true;
+    return false;
+  }
 };
 
 struct YeeConfig {
@@ -195,6 +200,8 @@ class YeeAssembler {
   double dielFracAt(const YeeField& F, size_t diel, int comp, const int c[3]) const;
   void stencilNormal(int comp0, const int cell[3], const int scomps[9], const int scells[9][3], double n[3]) const;
   void tupleUpdate(const int comps[3], const int cells[3][3], const double n[3], double out[3][3]) const;
+  void tupleUpdateC(const int comps[3], const int cells[3][3], const double n[3], std::complex<double> out[3][3]) const;
+  bool lossy_ = false;
   void setMap(YeeField& F);
   struct Entry { int comp; int off[3]; double val; };
   Csr<S> assemble(const YeeField& rowF, const YeeField& colF, bool skipDeadRows,

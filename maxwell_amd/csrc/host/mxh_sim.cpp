@@ -69,7 +69,7 @@ std::shared_ptr<const mx::Shape> mxh_parse_shape(const char* spec) {
   return inter;
 }
 
-// "e11,e22,e33[,o0,o1,o2] : shape-spec | ..." -> dielectrics; the off-diagonal triple follows the deck's
+// "e11,e22,e33[,o0,o1,o2] [tan=t] : shape-spec | ..." -> dielectrics (t: loss tangent, eps_ii (1 + i t)); the off-diagonal triple follows the deck's
 // `eps off diag`: eps(1,2) = o0, eps(0,2) = o1, eps(0,1) = o2 (src/MxProblem.cpp:516-518)
 std::vector<mx::YeeDielectric> mxh_parse_dielectrics(const char* spec) {
   std::vector<mx::YeeDielectric> out;
@@ -84,12 +84,16 @@ std::vector<mx::YeeDielectric> mxh_parse_dielectrics(const char* spec) {
     if (item.find_first_not_of(" \t\n") == std::string::npos) continue;
     const size_t colon = item.find(':');
     if (colon == std::string::npos) throw std::runtime_error("dielectric '" + item + "': expected 'eps : shape'");
-    const std::vector<double> e = numbers(item.substr(0, colon));
+    std::string head = item.substr(0, colon);
+    double losstan = 0.0;                                                   // optional "tan=<loss tangent>"
+    const size_t tpos = head.find("tan=");
+    if (tpos != std::string::npos) { losstan = atof(head.c_str() + tpos + 4); head = head.substr(0, tpos); }
+    const std::vector<double> e = numbers(head);
     if (e.size() != 3 && e.size() != 6) throw std::runtime_error("dielectric '" + item + "': 3 or 6 permittivity numbers");
     mx::YeeDielectric d;
     d.name = "dielectric" + std::to_string(out.size());                 // src/MxProblem.cpp:493-494
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d.eps[i][j] = 0.0;
-    for (int i = 0; i < 3; ++i) d.eps[i][i] = e[(size_t)i];
+    for (int i = 0; i < 3; ++i) { d.eps[i][i] = e[(size_t)i]; d.epsIm[i][i] = e[(size_t)i] * losstan; }
     if (e.size() == 6) {
       d.eps[0][1] = d.eps[1][0] = e[5];
       d.eps[0][2] = d.eps[2][0] = e[4];

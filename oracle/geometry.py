@@ -130,7 +130,7 @@ class HalfSpace(Shape):
     def __init__(self, point, normal):
         super().__init__()
         n = np.asarray(normal, dtype=float)
-        self.n = (n / np.linalg.norm(n)).tolist()
+        self.n = (n / _norm3(n)).tolist()
         self.translate(point)
 
     def _func(self, q):
@@ -151,7 +151,7 @@ class Cylinder(Shape):
     def __init__(self, radius, axis, location):
         super().__init__()
         a = np.asarray(axis, dtype=float)
-        a = a / np.linalg.norm(a)
+        a = a / _norm3(a)
         self.r2 = radius * radius
         self.P = (np.eye(3) - np.outer(a, a)).tolist()
         self.translate(location)
@@ -233,7 +233,7 @@ class Slab(Shape):
     def __init__(self, thickness, normal, midpoint):
         super().__init__()
         n = np.asarray(normal, dtype=float)
-        n = n / np.linalg.norm(n)
+        n = n / _norm3(n)
         self.slab = Intersection([HalfSpace(-0.5 * thickness * n, n),
                                   HalfSpace(0.5 * thickness * n, -n)])
         self.translate(midpoint)
@@ -257,6 +257,12 @@ def pillbox(radius=0.4, length=0.8):
 # ----------------------------------------------------------------------------
 # scalar helpers (Python float triples)
 # ----------------------------------------------------------------------------
+def _norm3(v):
+    """sqrt(v0^2 + v1^2 + v2^2) in this order (np.linalg.norm scales and may differ in the last bit)."""
+    import math
+    return math.sqrt(float(v[0]) * float(v[0]) + float(v[1]) * float(v[1]) + float(v[2]) * float(v[2]))
+
+
 def _row3(r, v):
     return r[0] * v[0] + r[1] * v[1] + r[2] * v[2]
 

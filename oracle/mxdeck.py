@@ -140,9 +140,10 @@ class Deck:
                 name = get_attr("name", child, "dielectric%d" % len(self.dielectrics))
                 diag = vec(get_attr("eps diag", child, "[1.0, 1.0, 1.0]"))
                 off = vec(get_attr("eps off diag", child, "[0.0, 0.0, 0.0]"))
-                if float(get_attr("loss tangent", child, "0.0")) != 0.0:
-                    raise ValueError("loss tangent: complex permittivity is not restated")
-                eps = np.diag(diag)
+                losstan = float(get_attr("loss tangent", child, "0.0"))
+                eps = np.diag(diag) if losstan == 0.0 else np.diag([complex(v, v * losstan) for v in diag])
+                if losstan != 0.0:
+                    self.params["is complex"] = True
                 eps[0, 1] = eps[1, 0] = off[2]
                 eps[0, 2] = eps[2, 0] = off[1]
                 eps[1, 2] = eps[2, 1] = off[0]

@@ -71,7 +71,7 @@ class YeeSim:
         self.strict = strict
         self.dm_frac = float(dm_frac)   # <PEC> 'D-M frac', src/MxProblem.cpp:450
         self.phase = np.exp(1j * np.array(phase_shifts, dtype=float))   # src/MxGridField.cpp:34-38
-        self.is_complex = bool(np.any(np.array(phase_shifts) != 0.0))
+        self.is_complex = bool(np.any(np.array(phase_shifts) != 0.0))   # or lossy dielectrics, set below
         lower = [_bc(x) for x in lower]
         upper = [_bc(x) for x in upper]
 
@@ -81,7 +81,14 @@ class YeeSim:
         P = _Field("psifield", 1, np.array([[half, half, half]]), [None])
         self.B, self.E, self.P = B, E, P
         # dielectrics: (shape, 3x3 real symmetric eps, name), src/MxProblem.cpp:487-527 / MxDielectric.cpp
-        self.dielectrics = [(sh, np.array(eps, dtype=float).reshape(3, 3), name) for sh, eps, name in dielectrics]
+        self.dielectrics = []
+        for sh, eps, name in dielectrics:
+            e = np.array(eps).reshape(3, 3)
+            # a loss tangent makes eps complex (src/MxProblem.cpp:505-513): keep floats otherwise
+            e = e.astype(complex) if np.iscomplexobj(e) and np.any(e.imag != 0.0) else e.real.astype(float)
+            self.dielectrics.append((sh, e, name))
+        self.lossy = any(np.iscomplexobj(e) for _, e, _ in self.dielectrics)
+        self.is_complex = self.is_complex or self.lossy
         # D lives where E lives (MxYeeElecFieldBase) but is represented by the dual face
         # (src/MxYeeFitDField.cpp:42-52); only built with dielectrics (src/MxEMSim.cpp:83-88)
         D = _Field("dfield", 3, E.coords.copy(), [0, 1, 2]) if self.dielectrics else None
@@ -424,6 +431,79 @@ class YeeSim:
         pi = geo._matmul3(eps, gamma)
         return gamma, pi
 
+    # complex permittivity: the same formulas with explicit complex division (the naive quotient; language
+    # runtimes differ in how they scale it), products and sums as the native (naive) complex operations
+    @staticmethod
+    def _cdiv(a, b):
+        a = complex(a); b = complex(b)
+        den = b.real * b.real + b.imag * b.imag
+        return complex((a.real * b.real + a.imag * b.imag) / den, (a.imag * b.real - a.real * b.imag) / den)
+
+    @classmethod
+    def _matmul3c(cls, x, y):
+        out = [[0j] * 3 for _ in range(3)]
+        for i in range(3):
+            for j in range(3):
+                acc = 0j
+                for k in range(3):
+                    acc = acc + complex(x[i][k]) * complex(y[k][j])
+                out[i][j] = acc
+        return out
+
+    @classmethod
+    def _inverse3c(cls, a):
+        a = [[complex(v) for v in row] for row in a]
+        det = (a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) -
+               a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+               a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]))
+        d = cls._cdiv
+        return [[d(a[1][1] * a[2][2] - a[1][2] * a[2][1], det), d(a[0][2] * a[2][1] - a[0][1] * a[2][2], det),
+                 d(a[0][1] * a[1][2] - a[0][2] * a[1][1], det)],
+                [d(a[1][2] * a[2][0] - a[1][0] * a[2][2], det), d(a[0][0] * a[2][2] - a[0][2] * a[2][0], det),
+                 d(a[0][2] * a[1][0] - a[0][0] * a[1][2], det)],
+                [d(a[1][0] * a[2][1] - a[1][1] * a[2][0], det), d(a[0][1] * a[2][0] - a[0][0] * a[2][1], det),
+                 d(a[0][0] * a[1][1] - a[0][1] * a[1][0], det)]]
+
+    @classmethod
+    def _gamma_pi_c(cls, eps, n):
+        eps = [[complex(v) for v in row] for row in eps]
+        nc = [complex(v, 0.0) for v in n]
+        epsn = [eps[i][0] * nc[0] + eps[i][1] * nc[1] + eps[i][2] * nc[2] for i in range(3)]
+        denom = nc[0] * epsn[0] + nc[1] * epsn[1] + nc[2] * epsn[2]
+        ime = [[complex(1.0 if i == j else 0.0, 0.0) - eps[i][j] for j in range(3)] for i in range(3)]
+        nn = [[nc[i] * nc[j] for j in range(3)] for i in range(3)]
+        prod = cls._matmul3c(nn, ime)
+        gamma = [[complex(1.0 if i == j else 0.0, 0.0) + cls._cdiv(prod[i][j], denom) for j in range(3)] for i in range(3)]
+        pi = cls._matmul3c(eps, gamma)
+        return gamma, pi
+
+    def _tuple_update_c(self, comps, cells, normal):
+        ave_g = [[0j] * 3 for _ in range(3)]
+        ave_p = [[0j] * 3 for _ in range(3)]
+        lsum, asum = [0.0] * 3, [0.0] * 3
+        bg = [[1.0 if i == j else 0.0 for j in range(3)] for i in range(3)]
+        for sh, eps, name in self.dielectrics:
+            lf, af = [0.0] * 3, [0.0] * 3
+            for j in range(3):
+                c = comps[j]
+                cell = np.array(cells[j])
+                lf[c] = float(self.frac_at(self.E, c, cell, name))
+                af[c] = float(self.frac_at(self.D, c, cell, name))
+                lsum[c] += lf[c]
+                asum[c] += af[c]
+            gamma, pi = self._gamma_pi_c(eps.tolist(), normal)
+            for j in range(3):
+                for k in range(3):
+                    ave_g[j][k] = ave_g[j][k] + complex(lf[j], 0.0) * gamma[j][k]
+                    ave_p[j][k] = ave_p[j][k] + complex(af[j], 0.0) * pi[j][k]
+        gamma, pi = self._gamma_pi_c(bg, normal)
+        for j in range(3):
+            lfj, afj = 1.0 - lsum[j], 1.0 - asum[j]
+            for k in range(3):
+                ave_g[j][k] = ave_g[j][k] + complex(lfj, 0.0) * gamma[j][k]
+                ave_p[j][k] = ave_p[j][k] + complex(afj, 0.0) * pi[j][k]
+        return self._matmul3c(ave_g, self._inverse3c(ave_p))
+
     def _tuple_update(self, comps, cells, normal):
         """tupleUpdate, src/MxYeeFitInvEps.cpp:305-385: length-fraction weighted rows of gamma times the
         inverse of area-fraction weighted rows of pi, over the dielectrics and the background."""
@@ -486,7 +566,9 @@ class YeeSim:
                 eps_diag, eps_here = True, np.eye(3)
             if eps_diag:                                                # :505-512
                 fac = self.factor(D, comp0, cell[None, :])[0]
-                rows.append(r); cols.append(r); vals.append((fac / eps_here[comp0, comp0]).real)
+                ecc = eps_here[comp0, comp0]
+                v = self._cdiv(fac, ecc) if self.lossy else complex(fac) / float(ecc.real)
+                rows.append(r); cols.append(r); vals.append(v)
                 continue
             comp1, comp2 = (comp0 + 1) % 3, (comp0 + 2) % 3            # getStencil, :35-71
             scomps = [comp0] + [comp1] * 4 + [comp2] * 4
@@ -510,17 +592,21 @@ class YeeSim:
             svals = [0.0] * 9
             nt = float(len(tuples))
             for t in tuples:                                            # :519-531
-                m = self._tuple_update([scomps[si] for si in t], [scells[si] for si in t], normal)
+                tc, tl = [scomps[si] for si in t], [scells[si] for si in t]
+                m = self._tuple_update_c(tc, tl, normal) if self.lossy else self._tuple_update(tc, tl, normal)
                 for si in t:
                     svals[si] += m[comp0][scomps[si]] / nt
             for si in range(9):                                         # :533-537
-                fac = self.factor(D, scomps[si], scells[si][None, :])[0].real
+                fac = complex(self.factor(D, scomps[si], scells[si][None, :])[0])
                 g = self.gid(D, scomps[si], scells[si][None, :])
                 pos, ok = self.lid(D, g)
                 if ok[0]:
                     rows.append(r); cols.append(int(pos[0])); vals.append(svals[si] * fac)
         n = len(E.gids)
-        m = sp.coo_matrix((np.array(vals, dtype=float), (rows, cols)), shape=(n, n)).tocsr()
+        vals = np.array(vals, dtype=complex)
+        if not self.is_complex:
+            vals = vals.real
+        m = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
         m.sum_duplicates(); m.sort_indices()
         return m
 
@@ -556,12 +642,28 @@ class YeeSim:
         """cellAveInvEpsOperator, src/MxYeeFitInvEps.cpp:700-790: volume-fraction average of
         3/trace(eps) on the Psi map (diagonal)."""
         P = self.P
-        out = np.zeros(len(P.gids)); sums = np.zeros(len(P.gids))
-        for sh, eps, nm in self.dielectrics:
-            fr = self.frac_at(P, 0, P.cells, nm)
-            sums = sums + fr
-            out = out + fr * (3.0 / (eps[0, 0] + eps[1, 1] + eps[2, 2]))
-        out = out + (1.0 - sums) * (3.0 / 3.0)
+        if not self.lossy:
+            out = np.zeros(len(P.gids)); sums = np.zeros(len(P.gids))
+            for sh, eps, nm in self.dielectrics:
+                fr = self.frac_at(P, 0, P.cells, nm)
+                sums = sums + fr
+                out = out + fr * (3.0 / (eps[0, 0] + eps[1, 1] + eps[2, 2]))
+            out = out + (1.0 - sums) * (3.0 / 3.0)
+            if self.is_complex:
+                out = out.astype(complex)
+            return sp.diags(out, format="csr")
+        # complex permittivity: scalar loop with the explicit quotient (no vectorised complex arithmetic)
+        fracs = [self.frac_at(P, 0, P.cells, nm) for _, _, nm in self.dielectrics]
+        scal = [self._cdiv(complex(3.0, 0.0), complex(eps[0, 0]) + complex(eps[1, 1]) + complex(eps[2, 2]))
+                for _, eps, _ in self.dielectrics]
+        out = np.zeros(len(P.gids), dtype=complex)
+        for r in range(len(P.gids)):
+            acc, sums = 0j, 0.0
+            for fr, sc in zip(fracs, scal):
+                f = float(fr[r])
+                sums = sums + f
+                acc = acc + complex(f, 0.0) * sc
+            out[r] = acc + complex((1.0 - sums) * (3.0 / 3.0), 0.0)
         return sp.diags(out, format="csr")
 
     # ---------------------------------------------------------------- MxMagWaveOp matrices

@@ -192,3 +192,20 @@ def test_complex_decks_bloch_phase_shifts(ctx):
     want = yee.mag_wave_modes(deck.sim(strict=False).wave_ops(), deck.params["eigensolver : shift"], 4)
     assert np.isrealobj(want)
     assert np.abs(k2 - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (k2, want)
+
+
+def test_lossy_dielectric_sphere_complex_frequencies(ctx):
+    """Config 5's complex variant: loss tangent 1e-3 on the eps = 10 sphere - complex k^2 (damped modes) from the
+    complex non-Hermitian Krylov-Schur against the oracle's dense restatement."""
+    text = open(os.path.join(GOLDEN, "dsphmsph.mx")).read().replace(
+        "eps off diag = [0.0, 0.0, 0.0]", "eps off diag = [0.0, 0.0, 0.0]\n    loss tangent = 0.001").replace(
+        "resolution = [12, 12, 12]", "resolution = [10, 10, 10]").replace("type = amg", "type = ilu")
+    deck = mxdeck.Deck(text)
+    solver = mx.Problem(text=text).solver(ctx)
+    assert solver.solve() == 3
+    got = np.array(sorted((solver.result(i)["k2"] for i in range(3)), key=lambda z: z.real))
+    want = yee.mag_wave_modes(deck.sim().wave_ops(), deck.params["eigensolver : shift"], 3)
+    assert np.iscomplexobj(want) and np.all(want.imag < 0)
+    assert np.abs(got - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (got, want)
+    q = got.real / (2 * np.abs(got.imag))          # Q of k^2: 1 / (loss tangent x electric filling factor) > 1000
+    assert np.all(q > 1000) and np.all(q < 3000)

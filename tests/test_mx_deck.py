@@ -78,8 +78,6 @@ def test_body_line_wins_over_tag_attribute():
     ("<S>\n polarization = TE\n <BoundaryConditions>\n lower bcs = [pec, foo, pec]\n </BoundaryConditions>\n</S>",
      "Invalid lower boundary condition"),
     ("<S>\n polarization = TE\n <Dielectric>\n </Dielectric>\n</S>", "Dielectric"),
-    ("<S>\n polarization = TE\n <Dielectric>\n loss tangent = 0.01\n <Sphere>\n name = s\n </Sphere>\n </Dielectric>\n</S>",
-     "loss tangent"),
     ("<S>\n polarization = TE\n <Mu>\n </Mu>\n</S>", "<Mu>"),
     ("<S>\n polarization = TE\n <PEC>\n <Torus>\n name = t\n </Torus>\n </PEC>\n</S>", "Torus"),
     ("<S>\n polarization = TE\n <Eigensolver>\n <LinearSolver>\n <Preconditioner>\n type = foo\n </Preconditioner>\n"
@@ -154,3 +152,36 @@ def test_complex_deck_operators_bit_identical(name):
         assert np.iscomplexobj(a.data) and a.shape == b.shape
         d = a - b
         assert d.nnz == 0 or np.abs(d.data).max() == 0.0, opname
+
+
+def _complex_ops_same(text, strict=True):
+    deck = mxdeck.Deck(text)
+    assert deck.params["is complex"]
+    prob = mx.Problem(text=text, strict=strict)
+    assert prob.is_complex
+    for opname, ref in deck.sim(strict=strict).wave_ops().items():
+        a, b = prob.op(opname).tocsr(), ref.tocsr()
+        d = a - b
+        assert a.shape == b.shape and (d.nnz == 0 or np.abs(d.data).max() == 0.0), opname
+    return deck, prob
+
+
+def test_loss_tangent_makes_the_problem_complex():
+    """<Dielectric> `loss tangent` t: eps_ii (1 + i t) (src/MxProblem.cpp:505-513) - complex FIT inverse
+    permittivity (tupleUpdate in complex arithmetic), complex operators, bit-identical to the oracle."""
+    text = _text("dsphmsph.mx").replace("eps off diag = [0.0, 0.0, 0.0]", "eps off diag = [0.0, 0.0, 0.0]\n    loss tangent = 0.001")
+    text = text.replace("resolution = [12, 12, 12]", "resolution = [8, 8, 8]")
+    deck, prob = _complex_ops_same(text)
+    ie = prob.op("invEps")
+    assert np.abs(ie.data.imag).max() > 1e-5
+
+
+def test_complex_inverse_permittivity_with_bloch_phases():
+    """A tilted fibre in a periodic box with Bloch phases (strict=False keeps the wrap-around entries): stencil
+    members across the periodic seam carry e^{+-i phi} into the FIT inverse permittivity."""
+    text = _text("fiber.mx").replace("axis = [1.0, 0.0, 0.0]", "axis = [1.0, 0.4, 0.2]").replace("resolution = [2, 12, 12]", "resolution = [4, 10, 10]")
+    text = text.replace("lower bcs = [periodic, pec, pec]", "lower bcs = [periodic, periodic, pec]").replace(
+        "upper bcs = [periodic, pec, pec]", "upper bcs = [periodic, periodic, pec]").replace("phase shifts = [0.9, 0.0, 0.0]", "phase shifts = [0.9, -0.5, 0.0]")
+    deck, prob = _complex_ops_same(text, strict=False)
+    ie = prob.op("invEps")
+    assert np.abs(ie.data.imag).max() > 1e-3
