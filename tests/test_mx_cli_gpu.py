@@ -207,5 +207,5 @@ def test_lossy_dielectric_sphere_complex_frequencies(ctx):
     want = yee.mag_wave_modes(deck.sim().wave_ops(), deck.params["eigensolver : shift"], 3)
     assert np.iscomplexobj(want) and np.all(want.imag < 0)
     assert np.abs(got - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (got, want)
-    q = got.real / (2 * np.abs(got.imag))          # Q of k^2: 1 / (loss tangent x electric filling factor) > 1000
+    q = got.real / np.abs(got.imag)     # k^2 ~ omega^2 (1 - i/Q): Q = 1 / (loss tangent x electric filling factor) >= 1000
     assert np.all(q > 1000) and np.all(q < 3000)
