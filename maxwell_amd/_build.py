@@ -85,7 +85,7 @@ def build_host(force=False):
     libmxg = os.path.join(LIBDIR, "libmxg.so")
     deps = [d for d in _deps(src_dir) if not d.endswith(".so")]
     dev_stamp = open(libmxg + ".stamp").read() if os.path.exists(libmxg + ".stamp") else ""
-    if not force and not _stale(target, deps, dev_stamp):
+    if not force and not _stale(target, deps, dev_stamp) and os.path.exists(os.path.join(LIBDIR, "maxwell")):
         return target
     # -ffp-contract=off: assembled matrix values must not depend on FMA contraction
     cmd = ["g++", "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
