@@ -205,7 +205,8 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_stream(
 struct BlkDesc {
   long long base;   // rowptr[r0]
   int r0, nr, nnzb; // first row, rows, non-zeros of the block
-  int pad[3];
+  int rb;           // position of the block's 16-bit row offsets in roff[] (r0 + block number in row order)
+  int pad[2];
 };
 
 template <typename CFG>
@@ -484,12 +485,15 @@ typedef RgCfg<256, 3072> RgCfgB;   // rows up to 12 nnz stay at 256 rows per blo
 
 // DOT: additionally emit partial[b] = sum over the block's rows of y[row] * xdot[row] (the p.Ap of
 // CG fused into the product; one value per block, combined in block order by k_sum_partials)
-template <typename CFG, int CH, bool DOT = false>
+// HALO: columns >= nowned are ghosts and live in a separate buffer (column j at xghost + j * ldghost): the
+// owned part of x is read in place, no [owned | ghosts] copy is assembled.
+template <typename CFG, int CH, bool DOT = false, bool HALO = false>
 __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
     const BlkDesc* __restrict__ desc, long long nblocks, const long long* __restrict__ rowptr,
     const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y,
     const double* __restrict__ xdot = nullptr, double* __restrict__ partial = nullptr,
-    const unsigned short* __restrict__ roff = nullptr) {
+    const unsigned short* __restrict__ roff = nullptr, const double* __restrict__ xghost = nullptr,
+    long long ldghost = 0, int nowned = 0) {
   constexpr int SB = CFG::SBLK, EPT = CFG::EPT;
   __shared__ double sval[CFG::NNZ_BLK];
   __shared__ int scol[CFG::NNZ_BLK];
@@ -499,8 +503,12 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
   if (d.nnzb > CFG::NNZ_CAP) {
     for (int j = 0; j < X.k; ++j) {
       const double* x = X.col(j);
+      const double* xg = HALO ? xghost + j * ldghost : nullptr;
       double sr = 0.0;
-      for (long long q = d.base + threadIdx.x; q < d.base + d.nnzb; q += SB) sr += vals[q] * x[colidx[q]];
+      for (long long q = d.base + threadIdx.x; q < d.base + d.nnzb; q += SB) {
+        const int cc = colidx[q];
+        sr += vals[q] * ((HALO && cc >= nowned) ? xg[cc - nowned] : x[cc]);
+      }
       if (j > 0) __syncthreads();
       sval[threadIdx.x] = sr;
       __syncthreads();
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
   if ((int)threadIdx.x < d.nr) {
     if (roff) {
       // 16-bit in-block row offsets (rowptr[r] - base, block b starts at r0 + b): 2 B/row instead of 8
-      const unsigned short* ro = roff + d.r0 + b + threadIdx.x;
+      const unsigned short* ro = roff + d.rb + threadIdx.x;
       o0 = ro[0];
       o1 = ro[1];
     } else {
@@ -543,6 +551,7 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
   __syncthreads();
   for (int j = 0; j < X.k; ++j) {
     const double* __restrict__ x = X.col(j);
+    const double* __restrict__ xg = HALO ? xghost + j * ldghost : nullptr;
     double sum = 0.0;
     for (int q0 = o0; q0 < o1; q0 += CH) {
       double v[CH], xv[CH];
@@ -551,7 +560,8 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
         const bool on = q0 + i < o1;
         const int cc = on ? scol[q0 + i] : 0;
         v[i] = on ? sval[q0 + i] : 0.0;
-        xv[i] = on ? x[cc] : 0.0;
+        if (HALO) xv[i] = on ? (cc >= nowned ? xg[cc - nowned] : x[cc]) : 0.0;
+        else xv[i] = on ? x[cc] : 0.0;
       }
 #pragma unroll
       for (int i = 0; i < CH; ++i)
@@ -911,6 +921,7 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (!mxg_ctx_alive(a->ctx)) { delete a; return 0; }   // context already gone
   hipSetDevice(a->ctx->device);
   hipStreamSynchronize(a->ctx->stream);
+  if (a->ctx->comm_stream) hipStreamSynchronize(a->ctx->comm_stream);
   hipFree(a->d_rowptr); hipFree(a->d_colidx); hipFree(a->d_vals); hipFree(a->d_rowblk);
   hipFree(a->d_diag);
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
@@ -923,6 +934,7 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (a->d_send_idx) hipFree(a->d_send_idx);
   if (a->d_sendbuf) hipFree(a->d_sendbuf);
   if (a->d_xext) hipFree(a->d_xext);
+  if (a->d_ghost) hipFree(a->d_ghost);
   delete a;
   return 0;
 }
@@ -1070,6 +1082,7 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
     d.r0 = blk[b]; d.nr = blk[b + 1] - blk[b];
     d.base = host_rowptr[blk[b]];
     d.nnzb = (int)(host_rowptr[blk[b + 1]] - d.base);
+    d.rb = d.r0 + (int)b;
     desc[b] = d;
   }
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
@@ -1082,12 +1095,28 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
     for (size_t b = 0; b < desc.size(); ++b) {
       const BlkDesc& d = desc[b];
       if (d.nnzb > cap) continue;
-      for (int r = 0; r <= d.nr; ++r) roff[(size_t)d.r0 + b + r] = (unsigned short)(host_rowptr[d.r0 + r] - d.base);
+      for (int r = 0; r <= d.nr; ++r) roff[(size_t)d.rb + r] = (unsigned short)(host_rowptr[d.r0 + r] - d.base);
     }
     MXG_HIP(hipMalloc(&a->d_roff, sizeof(unsigned short) * roff.size()));
     MXG_HIP(hipMemcpyAsync(a->d_roff, roff.data(), sizeof(unsigned short) * roff.size(), hipMemcpyHostToDevice,
                            c->stream));
     MXG_HIP(hipStreamSynchronize(c->stream));
+  }
+  a->n_interior = (int64_t)desc.size();
+  if (geo == 10 && a->nghost > 0) {
+    // distributed matrix: blocks that touch no ghost column first - they run while the halo is in flight
+    std::vector<int32_t> ci((size_t)a->nnz);
+    if (a->nnz > 0)
+      MXG_HIP(hipMemcpy(ci.data(), a->d_colidx, sizeof(int32_t) * a->nnz, hipMemcpyDeviceToHost));
+    std::vector<BlkDesc> inner, outer;
+    for (const BlkDesc& d : desc) {
+      bool ghost = false;
+      for (long long q = d.base; q < d.base + d.nnzb && !ghost; ++q) ghost = ci[(size_t)q] >= a->ncols_owned;
+      (ghost ? outer : inner).push_back(d);
+    }
+    a->n_interior = (int64_t)inner.size();
+    desc = inner;
+    desc.insert(desc.end(), outer.begin(), outer.end());
   }
   MXG_HIP(hipMalloc(&a->d_blkdesc, sizeof(BlkDesc) * std::max<size_t>(desc.size(), 1)));
   if (!desc.empty())
@@ -1268,13 +1297,15 @@ static int halo_exchange(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, MvDesc* xext) 
   const int k = x->k;
   const int64_t next = a->ncols_owned + a->nghost;
   const int64_t ldx = ((next * w) + 31) & ~(int64_t)31;
-  if (k > a->halo_kcap) {
+  if (k > a->halo_kcap || !a->d_xext) {
     MXG_HIP(hipStreamSynchronize(c->stream));
+    MXG_HIP(hipStreamSynchronize(c->comm_stream));
     if (a->d_sendbuf) hipFree(a->d_sendbuf);
     if (a->d_xext) hipFree(a->d_xext);
+    if (a->d_ghost) { hipFree(a->d_ghost); a->d_ghost = nullptr; }
     MXG_HIP(hipMalloc(&a->d_sendbuf, sizeof(double) * std::max<int64_t>(a->nsend, 1) * w * k));
     MXG_HIP(hipMalloc(&a->d_xext, sizeof(double) * ldx * k));
-    a->halo_kcap = k;
+    a->halo_kcap = k;   // (d_ghost is re-created on demand by halo_start)
   }
   for (int j = 0; j < k; ++j) {
     double* dst = a->d_xext + ldx * j;
@@ -1308,6 +1339,73 @@ static int halo_exchange(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, MvDesc* xext) 
   return 0;
 }
 
+
+// Overlapped ghost import for the row-gather kernel: pack on the compute stream, send/receive on the
+// communication stream straight into the ghost buffer (owned x is never copied); the caller launches the
+// interior blocks, then waits for ev_halo before the blocks that read ghosts.
+static int halo_start(mxg_ctx* c, mxg_csr* a, const mxg_mv* x) {
+  const int k = x->k;
+  const int64_t ldg = (a->nghost + 31) & ~(int64_t)31;
+  if (k > a->halo_kcap || !a->d_ghost) {
+    MXG_HIP(hipStreamSynchronize(c->stream));
+    MXG_HIP(hipStreamSynchronize(c->comm_stream));
+    if (a->d_sendbuf) hipFree(a->d_sendbuf);
+    if (a->d_xext) { hipFree(a->d_xext); a->d_xext = nullptr; }
+    if (a->d_ghost) hipFree(a->d_ghost);
+    const int kk = std::max(k, a->halo_kcap);
+    MXG_HIP(hipMalloc(&a->d_sendbuf, sizeof(double) * std::max<int64_t>(a->nsend, 1) * kk));
+    MXG_HIP(hipMalloc(&a->d_ghost, sizeof(double) * std::max<int64_t>(ldg, 32) * kk));
+    a->halo_kcap = kk;
+    a->ldghost = ldg;
+  }
+  for (int j = 0; j < k && a->nsend > 0; ++j) {
+    const int grid = mxg_grid_for(a->nsend, 256, 1, 4 * c->num_cu);
+    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, c->stream, x->colptr(j),
+                       (const long long*)a->d_send_idx, (long long)a->nsend, 1, a->d_sendbuf + a->nsend * j);
+  }
+  MXG_HIP(hipGetLastError());
+  MXG_CHECK(c->comm != nullptr, "halo exchange needs an RCCL communicator (nranks > 1)");
+  MXG_HIP(hipEventRecord(c->ev_pack, c->stream));
+  MXG_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+  MXG_NCCL(ncclGroupStart());
+  for (int j = 0; j < k; ++j)
+    for (int p = 0; p < a->nneigh; ++p) {
+      const int64_t ns = a->send_off[p + 1] - a->send_off[p];
+      const int64_t nr = a->recv_off[p + 1] - a->recv_off[p];
+      if (ns > 0)
+        MXG_NCCL(ncclSend(a->d_sendbuf + a->nsend * j + a->send_off[p], ns, ncclDouble, a->neigh[p], c->comm, c->comm_stream));
+      if (nr > 0)
+        MXG_NCCL(ncclRecv(a->d_ghost + ldg * j + a->recv_off[p], nr, ncclDouble, a->neigh[p], c->comm, c->comm_stream));
+    }
+  MXG_NCCL(ncclGroupEnd());
+  MXG_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+  return 0;
+}
+
+// interior blocks, wait for the halo, boundary blocks (row-gather kernel, real scalars)
+template <bool DOT>
+static int launch_rowgather_halo(mxg_ctx* c, mxg_csr* a, const MvDesc& X, const MvDesc& Y, const double* xdot,
+                                 double* partial) {
+  const unsigned short* roff = (a->kernel & 0x40000) ? (const unsigned short*)a->d_roff : (const unsigned short*)nullptr;
+  const BlkDesc* desc = (const BlkDesc*)a->d_blkdesc;
+  const long long ni = a->n_interior, nb = a->npipe - a->n_interior;
+  if (ni > 0) {
+    const unsigned grid = (unsigned)(((ni + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
+    hipLaunchKernelGGL((k_spmv_rowgather<RgCfgA, 7, DOT, false>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream, desc, ni,
+                       (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, X, Y, xdot, partial, roff,
+                       (const double*)nullptr, 0LL, 0);
+  }
+  MXG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+  if (nb > 0) {
+    const unsigned grid = (unsigned)(((nb + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
+    hipLaunchKernelGGL((k_spmv_rowgather<RgCfgA, 7, DOT, true>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream, desc + ni, nb,
+                       (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, X, Y, xdot, partial ? partial + ni : nullptr, roff,
+                       (const double*)a->d_ghost, (long long)a->ldghost, (int)a->ncols_owned);
+  }
+  MXG_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg_mv* y) {
   mxg_csr* a = const_cast<mxg_csr*>(a_);
   MXG_CHECK(c && a && x && y, "mxg_csr_apply: NULL argument");
@@ -1320,7 +1418,16 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
             "mxg_csr_apply: scalar type mismatch");
   MvDesc X = x->desc();
   const MvDesc Y = y->desc();
-  if (a->nghost > 0 || a->nneigh > 0) {
+  const bool halo = a->nghost > 0 || a->nneigh > 0;
+  if (halo && !a->is_complex && a->pipe_geo == 10 && a->npipe > 0 && (a->kernel & 0x1030000) == 0x10000 &&
+      !(a->kernel & 0xC0C0) && x->base != y->base) {
+    // default kernel on a distributed matrix: overlapped ghost import, owned x read in place
+    MXG_TRY(halo_start(c, a, x));
+    if (a->nrows == 0) { MXG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0)); return 0; }
+    (void)hipGetLastError();
+    return launch_rowgather_halo<false>(c, a, X, Y, nullptr, nullptr);
+  }
+  if (halo) {
     MXG_TRY(halo_exchange(c, a, x, &X));
   } else if (x->base == y->base) {
     // possible aliasing (apply(x, x), src/MxMagWaveOp.cpp:650,1249): work from a copy of x,
@@ -1448,8 +1555,16 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
   MXG_CHECK(a->pipe_geo == 10 && a->npipe > 0, "mxg_dev_csr_apply_dot: row-gather descriptors missing");
   MvDesc X = x->desc();
   const MvDesc Y = y->desc();
-  if (a->nghost > 0 || a->nneigh > 0) MXG_TRY(halo_exchange(c, a, x, &X));
   if (!a->d_dotpartial) MXG_HIP(hipMalloc(&a->d_dotpartial, sizeof(double) * a->npipe));
+  if (a->nghost > 0 || a->nneigh > 0) {
+    MXG_TRY(halo_start(c, a, x));
+    (void)hipGetLastError();
+    MXG_TRY((launch_rowgather_halo<true>(c, a, X, Y, (const double*)x->colptr(0), a->d_dotpartial)));
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, (const double*)a->d_dotpartial,
+                       (long long)a->npipe, d_out);
+    MXG_HIP(hipGetLastError());
+    return 0;
+  }
   const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
   const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
   (void)hipGetLastError();

@@ -57,6 +57,9 @@ extern "C" int mxg_ctx_create(int device, int rank, int nranks, const void* nccl
   MXG_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   MXG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  MXG_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  MXG_HIP(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+  MXG_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
   MXG_HIP(hipEventCreate(&c->ev0));
   MXG_HIP(hipEventCreate(&c->ev1));
   MXG_CHECK(nranks == 1 || nccl_unique_id != nullptr, "mxg_ctx_create: nranks > 1 needs an RCCL unique id");
@@ -84,6 +87,9 @@ extern "C" int mxg_ctx_destroy(mxg_ctx* c) {
   if (c->d_scratch) hipFree(c->d_scratch);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
+  if (c->ev_pack) hipEventDestroy(c->ev_pack);
+  if (c->ev_halo) hipEventDestroy(c->ev_halo);
+  if (c->comm_stream) { hipStreamSynchronize(c->comm_stream); hipStreamDestroy(c->comm_stream); }
   hipStreamDestroy(c->stream);
   delete c;
   return 0;

@@ -59,6 +59,9 @@ struct mxg_ctx {
   hipStream_t stream = nullptr;
   ncclComm_t comm = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // halo exchange runs on its own stream so that interior rows overlap it (ev_pack / ev_halo order the two)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
   // reduction workspace: partial sums + results (device), results (pinned host)
   double* d_partial = nullptr;   // MXG_MAX_RED_BLOCKS * red_width doubles
   double* d_result = nullptr;    // red_width doubles
@@ -146,7 +149,10 @@ struct mxg_csr {
   int64_t* d_send_idx = nullptr;
   int64_t nsend = 0;
   double* d_sendbuf = nullptr;   // nsend * kcap scalars
-  double* d_xext = nullptr;      // (ncols_owned + nghost) * kcap scalars: x with ghosts appended
+  double* d_xext = nullptr;      // (ncols_owned + nghost) * kcap scalars: x with ghosts appended (kernels without the split)
+  double* d_ghost = nullptr;     // nghost * kcap scalars: received ghosts only (row-gather kernel reads owned x in place)
+  int64_t ldghost = 0;
+  int64_t n_interior = 0;        // row-gather descriptors [0, n_interior) reference no ghost column
   int halo_kcap = 0;
 };
 

@@ -229,6 +229,34 @@ def test_halo_exchange_on_a_one_rank_communicator(built, oracle_pillbox12, rng):
         X = mx.MultiVec.from_numpy(ctx1, x); Y = mx.MultiVec(ctx1, n, 2)
         A.apply(X, Y)
         assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+        # default kernel: interior blocks run while the ghosts travel on the communication stream, the blocks
+        # that read ghosts follow; repeated products re-use the ghost buffer
+        for rep in range(3):
+            x2 = rng.uniform(-1, 1, (n, 1))
+            X2 = mx.MultiVec.from_numpy(ctx1, x2); Y2 = mx.MultiVec(ctx1, n, 1)
+            A.apply(X2, Y2)
+            assert np.array_equal(Y2.to_numpy(), cref.spmv(m, x2))
+        # kernels without the interior/boundary split assemble [owned | ghosts] (stream kernel), then back
+        A.set_kernel(0x0)
+        A.apply(X, Y)
+        assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+        A.set_kernel(0x750000)
+        A.apply(X, Y)
+        assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+        # fused CG (SpMV + dot with the halo in flight) on the ghosted matrix
+        spd = (m + m.T).tocsr() * 0.5 + sp.identity(n) * 40.0
+        cols2 = spd.indices.astype(np.int64).copy()
+        rer = (slot[cols2] >= 0) & (rng.uniform(0, 1, len(cols2)) < 0.7)
+        cols2[rer] = slot[cols2[rer]]
+        rp2 = np.ascontiguousarray(spd.indptr, dtype=np.int64); ci2 = np.ascontiguousarray(cols2, dtype=np.int32)
+        va2 = np.ascontiguousarray(spd.data)
+        S = mx.CsrMatrix(ctx1, n, n, rp2.ctypes.data_as(C.c_void_p), ci2.ctypes.data_as(C.c_void_p),
+                         va2.ctypes.data_as(C.c_void_p), False, nghost=len(ghosted), plan=C.byref(plan))
+        bvec = rng.uniform(-1, 1, n)
+        Bv = mx.MultiVec.from_numpy(ctx1, bvec); Xs = mx.MultiVec(ctx1, n, 1); Xs.fill(0.0)
+        it, conv, res = S.solve(Bv, Xs, method="cg", tol=1e-10, precond="jacobi")
+        assert conv and np.linalg.norm(spd @ Xs.to_numpy()[:, 0] - bvec) < 1e-8
+        S.close()
         # the collectives of C2 on the same communicator
         assert np.abs(X.norm2() - np.linalg.norm(x, axis=0)).max() < 1e-12
         ctx1.barrier()
