@@ -246,7 +246,8 @@ def test_halo_exchange_on_a_one_rank_communicator(built, oracle_pillbox12, rng):
         # fused CG (SpMV + dot with the halo in flight) on the ghosted matrix
         spd = (m + m.T).tocsr() * 0.5 + sp.identity(n) * 40.0
         cols2 = spd.indices.astype(np.int64).copy()
-        rer = (slot[cols2] >= 0) & (rng.uniform(0, 1, len(cols2)) < 0.7)
+        rows2 = np.repeat(np.arange(n), np.diff(spd.indptr))
+        rer = (slot[cols2] >= 0) & (rng.uniform(0, 1, len(cols2)) < 0.7) & (cols2 != rows2)   # a diagonal is never a ghost
         cols2[rer] = slot[cols2[rer]]
         rp2 = np.ascontiguousarray(spd.indptr, dtype=np.int64); ci2 = np.ascontiguousarray(cols2, dtype=np.int32)
         va2 = np.ascontiguousarray(spd.data)
