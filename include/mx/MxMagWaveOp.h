@@ -271,9 +271,9 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     const mx::YeeAssembler<double>& a = mSim->getAssembler();
     mxg_ctx* ctx = mBMap->getComm()->getCtx();
     if (mVecMg) mxh_mg_destroy(mVecMg);
-    mVecMg = mxh_mg_build(ctx, mShiftedVecLapl->getHostCsr(), a.bfield(), a.config().n, 2000, levels, sweeps, 30, 0.7, 1.9);
+    mVecMg = mxh_mg_build(ctx, mShiftedVecLapl->getHostCsr(), a.bfield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);
     if (mHasCurlNull && !mScaMg)
-      mScaMg = mxh_mg_build(ctx, mScaLapl->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.7, 1.9);
+      mScaMg = mxh_mg_build(ctx, mScaLapl->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);
   }
 
   int solve(mxg_ctx* ctx, mxg_csr* A, mxg_mv* b, mxg_mv* x, mxg_solve_info* info, mxh_mg* mg) const {

@@ -366,7 +366,7 @@ class Multigrid:
     ("scaLapl") of a Sim: hierarchy built on the host, V-cycle on the GPU."""
 
     def __init__(self, ctx, sim, op="shifted", shift=0.0, min_coarse=2000, max_levels=10, sweeps=2,
-                 coarse_sweeps=30, omega=0.7, coarse_scale=1.9):
+                 coarse_sweeps=30, omega=0.85, coarse_scale=1.9):
         self.lib = _lib.load_mxhost()
         self.ctx, self.sim = ctx, sim
         h = C.c_void_p()
