@@ -6,6 +6,8 @@
 #define MX_MG_HPP
 
 #include <algorithm>
+#include <cstdint>
+#include <utility>
 #include <vector>
 
 #include "mx/mx_sparse.hpp"
@@ -25,39 +27,45 @@ inline MgHierarchy buildAggregationHierarchy(const Csr<double>& A0, const UVec<i
   // lattice coordinates of every fine unknown
   int64_t dims[3] = {n[0] + 1, n[1] + 1, n[2] + 1};
   const int64_t nf0 = (int64_t)gids.size();
-  std::vector<int> comp(nf0);
-  std::vector<int64_t> ci(nf0), cj(nf0), ck(nf0);
+  UVec<int32_t> comp(nf0), ci(nf0), cj(nf0), ck(nf0);
+#pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < nf0; ++r) {
     const int64_t cell = gids[r] / ncomp;
-    comp[r] = (int)(gids[r] % ncomp);
-    ck[r] = cell % dims[2];
-    cj[r] = (cell / dims[2]) % dims[1];
-    ci[r] = cell / (dims[2] * dims[1]);
+    comp[r] = (int32_t)(gids[r] % ncomp);
+    ck[r] = (int32_t)(cell % dims[2]);
+    cj[r] = (int32_t)((cell / dims[2]) % dims[1]);
+    ci[r] = (int32_t)(cell / (dims[2] * dims[1]));
   }
   while ((int)h.A.size() < maxLevels && h.A.back().nrows > minCoarse) {
     const Csr<double>& A = h.A.back();
     const int64_t nf = A.nrows;
-    int64_t cd[3] = {(dims[0] + 1) / 2, (dims[1] + 1) / 2, (dims[2] + 1) / 2};
+    const int64_t cd[3] = {(dims[0] + 1) / 2, (dims[1] + 1) / 2, (dims[2] + 1) / 2};
     // unknowns with a zero diagonal (structurally empty rows: unused components that stay in the
     // map, reference src/MxYeeDeyMittraCurlE.cpp:148-150) take no part: they get no correction,
     // so they stay exactly zero like in the reference
-    std::vector<uint8_t> active(nf, 0);
-    for (int64_t i = 0; i < nf; ++i)
+    UVec<uint8_t> active(nf);
+    UVec<int64_t> key(nf);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nf; ++i) {
+      uint8_t act = 0;
       for (int64_t q = A.rowptr[i]; q < A.rowptr[i + 1]; ++q)
-        if (A.col[q] == i && A.val[q] != 0.0) active[i] = 1;
-    std::vector<int64_t> key(nf);
-    std::vector<int64_t> uniq;
-    for (int64_t r = 0; r < nf; ++r) {
-      key[r] = comp[r] + (int64_t)ncomp * (((ci[r] >> 1) * cd[1] + (cj[r] >> 1)) * cd[2] + (ck[r] >> 1));
-      if (active[r]) uniq.push_back(key[r]);
+        if (A.col[q] == i && A.val[q] != 0.0) act = 1;
+      active[i] = act;
+      key[i] = comp[i] + (int64_t)ncomp * ((((int64_t)ci[i] >> 1) * cd[1] + (cj[i] >> 1)) * cd[2] + (ck[i] >> 1));
     }
-    std::sort(uniq.begin(), uniq.end());
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    const int64_t nc = (int64_t)uniq.size();
+    // aggregates numbered in ascending key order: flag the keys in use over the dense coarse lattice, prefix sum
+    const int64_t nkeys = (int64_t)ncomp * cd[0] * cd[1] * cd[2];
+    UVec<int32_t> number(nkeys + 1);
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k <= nkeys; ++k) number[k] = 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < nf; ++r) if (active[r]) number[key[r]] = 1;   // benign race: every writer stores 1
+    int64_t nc = 0;
+    for (int64_t k = 0; k < nkeys; ++k) { const int32_t f = number[k]; number[k] = (int32_t)nc; nc += f; }
     if (nc == 0 || nc >= nf) break;
-    std::vector<int32_t> agg(nf, -1);
-    for (int64_t r = 0; r < nf; ++r)
-      if (active[r]) agg[r] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), key[r]) - uniq.begin());
+    UVec<int32_t> agg(nf);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < nf; ++r) agg[r] = active[r] ? number[key[r]] : -1;
     // P: one unit entry per active fine row
     Csr<double> P;
     P.nrows = nf; P.ncols = nc;
@@ -65,32 +73,72 @@ inline MgHierarchy buildAggregationHierarchy(const Csr<double>& A0, const UVec<i
     P.rowptr[0] = 0;
     for (int64_t r = 0; r < nf; ++r) P.rowptr[r + 1] = P.rowptr[r] + (active[r] ? 1 : 0);
     P.col.resize(P.rowptr[nf]); P.val.resize(P.rowptr[nf]);
+#pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < nf; ++r) if (active[r]) { P.col[P.rowptr[r]] = agg[r]; P.val[P.rowptr[r]] = 1.0; }
-    Csr<double> R = transpose(P);
-    // Galerkin coarse operator by relabelling the fine entries
-    std::vector<int64_t> tr;
-    std::vector<int32_t> tc;
-    std::vector<double> tv;
-    tr.reserve(A.nnz()); tc.reserve(A.nnz()); tv.reserve(A.nnz());
-    for (int64_t i = 0; i < nf; ++i) {
-      if (!active[i]) continue;
-      for (int64_t q = A.rowptr[i]; q < A.rowptr[i + 1]; ++q) {
-        if (!active[A.col[q]]) continue;
-        tr.push_back(agg[i]); tc.push_back(agg[A.col[q]]); tv.push_back(A.val[q]);
+    // R = P^T: the fine rows of every aggregate in ascending order (counting sort)
+    Csr<double> R;
+    R.nrows = nc; R.ncols = nf;
+    R.rowptr.resize(nc + 1);
+    for (int64_t a = 0; a <= nc; ++a) R.rowptr[a] = 0;
+    for (int64_t r = 0; r < nf; ++r) if (agg[r] >= 0) R.rowptr[agg[r] + 1]++;
+    for (int64_t a = 0; a < nc; ++a) R.rowptr[a + 1] += R.rowptr[a];
+    R.col.resize(R.rowptr[nc]); R.val.resize(R.rowptr[nc]);
+    {
+      UVec<int64_t> pos(R.rowptr.begin(), R.rowptr.end() - 1);
+      for (int64_t r = 0; r < nf; ++r)
+        if (agg[r] >= 0) { const int64_t q = pos[agg[r]]++; R.col[q] = (int32_t)r; R.val[q] = 1.0; }
+    }
+    // Galerkin coarse operator R A P, one coarse row at a time: relabel the entries of the aggregate's fine
+    // rows (fine-row order, then storage order), sort by coarse column, sum repeated columns in that order
+    Csr<double> Ac;
+    Ac.nrows = nc; Ac.ncols = nc;
+    Ac.rowptr.resize(nc + 1);
+    UVec<int64_t> cnt(nc);
+    auto gatherRow = [&](int64_t a, std::vector<std::pair<int32_t, double> >& buf) {
+      buf.clear();
+      for (int64_t t = R.rowptr[a]; t < R.rowptr[a + 1]; ++t) {
+        const int64_t i = R.col[t];
+        for (int64_t q = A.rowptr[i]; q < A.rowptr[i + 1]; ++q) {
+          const int32_t c = agg[A.col[q]];
+          if (c >= 0) buf.emplace_back(c, A.val[q]);
+        }
+      }
+      std::stable_sort(buf.begin(), buf.end(), [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) { return x.first < y.first; });
+      size_t w = 0;
+      for (size_t x = 0; x < buf.size(); ++x) {
+        if (w > 0 && buf[w - 1].first == buf[x].first) buf[w - 1].second += buf[x].second;
+        else buf[w++] = buf[x];
+      }
+      buf.resize(w);
+    };
+#pragma omp parallel
+    {
+      std::vector<std::pair<int32_t, double> > buf;
+#pragma omp for schedule(dynamic, 1024)
+      for (int64_t a = 0; a < nc; ++a) { gatherRow(a, buf); cnt[a] = (int64_t)buf.size(); }
+    }
+    Ac.rowptr[0] = 0;
+    for (int64_t a = 0; a < nc; ++a) Ac.rowptr[a + 1] = Ac.rowptr[a] + cnt[a];
+    Ac.col.resize(Ac.rowptr[nc]); Ac.val.resize(Ac.rowptr[nc]);
+#pragma omp parallel
+    {
+      std::vector<std::pair<int32_t, double> > buf;
+#pragma omp for schedule(dynamic, 1024)
+      for (int64_t a = 0; a < nc; ++a) {
+        gatherRow(a, buf);
+        for (size_t x = 0; x < buf.size(); ++x) { Ac.col[Ac.rowptr[a] + x] = buf[x].first; Ac.val[Ac.rowptr[a] + x] = buf[x].second; }
       }
     }
-    Csr<double> Ac = fromTriplets<double>(nc, nc, tr, tc, tv);
     // coordinates of the coarse unknowns
-    std::vector<int> ncomp_c(nc);
-    std::vector<int64_t> ni(nc), nj(nc), nk(nc);
-    for (int64_t r = 0; r < nf; ++r) {
-      const int32_t a = agg[r];
-      if (a < 0) continue;
+    UVec<int32_t> ncomp_c(nc), ni(nc), nj(nc), nk(nc);
+#pragma omp parallel for schedule(static)
+    for (int64_t a = 0; a < nc; ++a) {
+      const int64_t r = R.col[R.rowptr[a]];
       ncomp_c[a] = comp[r]; ni[a] = ci[r] >> 1; nj[a] = cj[r] >> 1; nk[a] = ck[r] >> 1;
     }
     comp.swap(ncomp_c); ci.swap(ni); cj.swap(nj); ck.swap(nk);
     dims[0] = cd[0]; dims[1] = cd[1]; dims[2] = cd[2];
-    h.P.push_back(P); h.R.push_back(R); h.A.push_back(Ac);
+    h.P.push_back(std::move(P)); h.R.push_back(std::move(R)); h.A.push_back(std::move(Ac));
   }
   return h;
 }
