@@ -69,6 +69,19 @@ class MxEMOps {
     if (store) mOps[name] = res;
     return res;
   }
+  // adopt an operator assembled elsewhere (MxEMSim::prebuiltOps); maps follow from the operator's role
+  void adopt(std::string const& name, mx::Csr<Scalar> const& m) {
+    RCP<MxMap> b = mSim->getField("bfield").getMap(), e = mSim->getField("efield").getMap(),
+               p = mSim->getField("psifield").getMap();
+    RCP<MxMap> rows = b, cols = b;
+    if (name == "curlE") { cols = e; }
+    else if (name == "curlB") { rows = e; }
+    else if (name == "divB") { rows = p; }
+    else if (name == "gradPsi") { cols = p; }
+    else if (name == "dmL" || name == "invEps") { rows = e; cols = e; }
+    else if (name == "dmVInv" || name == "invEpsVolAve" || name == "scaLapl") { rows = p; cols = p; }
+    mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, m));
+  }
   void saveOps() const { for (auto& e : mOps) e.second->save("Mx" + e.first); }
  private:
   void insert(const char* name, RCP<MxMap> rows, RCP<MxMap> cols, mx::Csr<Scalar> const& m) {

@@ -76,6 +76,12 @@ class MxEMSim {
     mPList.set("has curl null", true);
   }
   bool isComplex() const { return mComplex; }
+  // operators already assembled for this configuration (the mxh_sim of the C ABI computes the whole chain for
+  // export); MxMagWaveOp::initMatrices adopts them instead of repeating the products.  Real problems only.
+  typedef std::map<std::string, mx::Csr<double> > OpCache;
+  void setPrebuiltOps(const OpCache* ops) { mPrebuilt = ops; }
+  const OpCache* prebuiltOps(double*) const { return mPrebuilt; }
+  const OpCache* prebuiltOps(MxComplex*) const { return nullptr; }
   bool hasPEC() const { return (bool)mCfg.pec; }
   bool hasDielectric() const { return !mCfg.dielectrics.empty(); }
   bool hasMu() const { return false; }
@@ -117,6 +123,7 @@ class MxEMSim {
   MxGrid<DIM> mGrid;
   Teuchos::ParameterList mPList;
   bool mComplex = false;
+  const OpCache* mPrebuilt = nullptr;
   std::shared_ptr<mx::YeeAssembler<double> > mAsm;
   mutable std::shared_ptr<mx::YeeAssembler<MxComplex> > mAsmC;
   std::map<std::string, std::shared_ptr<MxGridField<DIM> > > mFields;

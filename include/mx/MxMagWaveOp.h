@@ -166,6 +166,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   static Scalar toScalar(std::complex<double> z) { return toScalarImpl(z, (Scalar*)0); }
 
   void initMatrices() {   // :138-245
+    if (adoptPrebuilt((Scalar*)0)) return;
     mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim));
     std::vector<std::string> names;
     names.push_back("curlB");
@@ -202,6 +203,19 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     }
     if (mSim->hasPEC()) mRhs = mEMOps->getOp("dmA");
     else mRhs = rcp(new MxCrsMatrix<Scalar>(mBMap, ScalarTraits<Scalar>::one()));
+  }
+
+  // the operator chain was already formed for this configuration (mxh_sim): adopt it, same matrices bit for bit
+  bool adoptPrebuilt(MxComplex*) { return false; }
+  bool adoptPrebuilt(double*) {
+    const typename MxEMSim<DIM>::OpCache* pre = mSim->prebuiltOps((double*)0);
+    if (!pre || !pre->count("vecLapl") || !pre->count("scaLapl") || !pre->count("mRhs")) return false;
+    mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim, false));
+    for (auto const& e : *pre) mEMOps->adopt(e.first, e.second);
+    mVecLapl = mEMOps->getOp("vecLapl");
+    mScaLapl = mEMOps->getOp("scaLapl");
+    mRhs = mEMOps->getOp("mRhs");
+    return true;
   }
 
   void initWorkVecs() { ensureWork((size_t)blockSize); }

@@ -18,6 +18,7 @@ void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::Parame
   s.comm = rcp(new MxComm(ctx));
   s.params.shift = pl.get("eigensolver : shift", 0.0);
   s.sim = rcp(new MxEMSim<3>(sim->cfg, s.comm, pl, sim->asmb));
+  s.sim->setPrebuiltOps(&sim->ops);     // the chain of products was formed when the sim was created
   s.solver.reset(new MxSolver<3, double>(s.sim, pl));
 }
 
