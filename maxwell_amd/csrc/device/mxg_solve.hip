@@ -106,7 +106,7 @@ __global__ void k_cg_update(long long n, double* __restrict__ x, double* __restr
     r[i] = ri;
     double zi = ri;
     if (diag) { const double d = diag[i]; zi = d != 0.0 ? ri / d : 0.0; }
-    z[i] = zi;
+    if (z) z[i] = zi;          // z == nullptr: the preconditioner (multigrid) forms z afterwards
     srz += ri * zi;
     srr += ri * ri;
   }
@@ -291,13 +291,17 @@ extern "C" int mxg_mg_apply(mxg_ctx* c, mxg_mg* mg, const mxg_mv* r, mxg_mv* z) 
 namespace {
 
 bool cg_fused_ok(const mxg_csr* A, const mxg_solve_opts* o) {
-  return !A->is_complex && A->pipe_geo == 10 && A->npipe > 0 && (A->kernel & 0x30000) && o->precond <= 1;
+  return !A->is_complex && A->pipe_geo == 10 && A->npipe > 0 && (A->kernel & 0x30000) &&
+         (o->precond <= 1 || (o->precond == 3 && o->mg != nullptr));
 }
 
 // one right-hand side; x: initial guess in, solution out.  r, z, p, q: work vectors.
 int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, mxg_mv* x, mxg_mv* r,
              mxg_mv* z, mxg_mv* p, mxg_mv* q, int max_iters, int* iters, double* res_out) {
-  constexpr int CHUNK = 16;
+  // multigrid-preconditioned CG converges in a few dozen 2-3 ms iterations: test every iteration;
+  // Jacobi / plain CG runs thousands of sub-ms iterations: test every 16
+  const bool mgprec = o->precond == 3;
+  const int CHUNK = mgprec ? 1 : 16;
   const long long n = A->nrows;
   const int grid = mxg_grid_for(n, CGB, 4, 1024);
   double* scal = c->d_result;
@@ -324,10 +328,14 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
         MXG_TRY(mxg_dev_csr_apply_dot(c, A, p, q, scal + S_PQ));
         MXG_TRY(allreduce(scal + S_PQ, 1));
         hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(CGB), 0, c->stream, n, x->colptr(0), r->colptr(0),
-                           (const double*)p->colptr(0), (const double*)q->colptr(0), z->colptr(0), diag,
-                           (const double*)scal, cur, c->d_partial);
+                           (const double*)p->colptr(0), (const double*)q->colptr(0),
+                           mgprec ? (double*)nullptr : z->colptr(0), diag, (const double*)scal, cur, c->d_partial);
         hipLaunchKernelGGL(k_cg_reduce2, dim3(2), dim3(CGB), 0, c->stream, (const double*)c->d_partial, grid,
                            scal, nxt);
+        if (mgprec) {            // z = V-cycle(r), r.z replaces the placeholder the update kernel left in slot nxt
+          MXG_TRY(apply_prec(c, A, o, r, z));
+          MXG_TRY(mxg_dev_dot(c, r->desc(), z->desc(), scal + nxt));
+        }
         if (c->comm) {   // r.z and r.r sit in different slots: two tiny all-reduces
           MXG_TRY(allreduce(scal + nxt, 1));
           MXG_TRY(allreduce(scal + S_RR, 1));
