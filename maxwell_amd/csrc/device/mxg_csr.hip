@@ -611,15 +611,18 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 // EPI: 0  y = A x
 //      1  y = x + omega (rhs - A x) / diag   (one damped-Jacobi sweep; rows with diag == 0 keep x)
 //      2  y = rhs - A x                      (residual)
+//      3  y = y + omega A x                  (coarse-grid correction in place: A = prolongation)
 // (multigrid smoother / residual fused into the product: no separate pass over the vectors)
 template <int EPI>
 __device__ inline double cs_epilogue(double ax, long long row, const double* __restrict__ x,
-                                     const double* __restrict__ rhs, const double* __restrict__ diag, double omega) {
+                                     const double* __restrict__ rhs, const double* __restrict__ diag, double omega,
+                                     const double* y) {
   if (EPI == 1) {
     const double dg = diag[row], xr = x[row];
     return dg != 0.0 ? xr + omega * (rhs[row] - ax) / dg : xr;
   }
   if (EPI == 2) return rhs[row] - ax;
+  if (EPI == 3) return y[row] + omega * ax;
   return ax;
 }
 
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
       double tr = 0.0;
 #pragma unroll 4
       for (int q = 0; q < SB; ++q) tr += svtab[q];   // (full unrolling of this cold loop would cost 256 VGPRs)
-      y[d.r0] = cs_epilogue<EPI>(tr, d.r0, x, rhs, diag, omega);
+      y[d.r0] = cs_epilogue<EPI>(tr, d.r0, x, rhs, diag, omega, y);
       if (DOT) partial[b] = tr * xdot[d.r0];
     }
     return;
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
   for (int r = 0; r < RPT; ++r) {
     const int row = t + r * SB;
     if (row < d.nr) {
-      __builtin_nontemporal_store(cs_epilogue<EPI>(sum[r], d.r0 + row, x, rhs, diag, omega), y + d.r0 + row);
+      __builtin_nontemporal_store(cs_epilogue<EPI>(sum[r], d.r0 + row, x, rhs, diag, omega, y), y + d.r0 + row);
       if (DOT) part += sum[r] * xdot[d.r0 + row];
     }
   }
@@ -1541,7 +1544,7 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
                      (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,        \
                      (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0), \
                      (const double*)nullptr, (double*)nullptr, rhs, diag, omega)
-  if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else MXG_CS_EPI(0);
+  if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else if (epi == 3) MXG_CS_EPI(3); else MXG_CS_EPI(0);
 #undef MXG_CS_EPI
   if (hipGetLastError() != hipSuccess) { mxg_set_error("mxg_dev_csr_apply_epi: launch failed"); return 2; }
   return 0;

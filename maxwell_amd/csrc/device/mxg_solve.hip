@@ -232,9 +232,14 @@ int mg_cycle(mxg_mg* mg, int l) {
   }
   MXG_TRY(mxg_csr_apply(c, mg->R[l], mg->t[l], mg->r[l + 1]));                    // restrict
   MXG_TRY(mg_cycle(mg, l + 1));
-  MXG_TRY(mxg_csr_apply(c, mg->P[l], mg->z[l + 1], mg->t[l]));                    // prolong
-  hipLaunchKernelGGL(k_axpy1, dim3(grid), dim3(256), 0, c->stream, n, mg->cscale,
-                     (const double*)mg->t[l]->colptr(0), mg->z[l]->colptr(0));
+  // z += cscale * P z_c: in the prolongation's epilogue when P is compressed (in place: a row reads only its own z)
+  const int rp = mxg_dev_csr_apply_epi(c, mg->P[l], mg->z[l + 1], mg->z[l], 3, nullptr, nullptr, mg->cscale);
+  if (rp > 1) return 1;
+  if (rp == 1) {
+    MXG_TRY(mxg_csr_apply(c, mg->P[l], mg->z[l + 1], mg->t[l]));                  // prolong
+    hipLaunchKernelGGL(k_axpy1, dim3(grid), dim3(256), 0, c->stream, n, mg->cscale,
+                       (const double*)mg->t[l]->colptr(0), mg->z[l]->colptr(0));
+  }
   MXG_HIP(hipGetLastError());
   return mg_smooth(mg, l, mg->post, false);
 }
