@@ -160,10 +160,6 @@ struct mxg_mg {
                                       // ping-pong partner of z for the fused sweeps)
   int pre = 2, post = 2, coarse = 20;
   double omega = 0.7, cscale = 1.9;
-  // levels [tail, nlevels) are small enough (<= MG_TAIL_ROWS rows) to run their part of the cycle inside ONE
-  // single-workgroup kernel instead of ~100 launch-latency-bound kernels per cycle; -1: no tail
-  int tail = -1;
-  void* d_tail = nullptr;             // device array of TailLevel
 };
 
 namespace {
@@ -197,74 +193,6 @@ __global__ void k_axpy1(long long n, double s, const double* __restrict__ t, dou
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) z[i] += s * t[i];
 }
 
-
-// ------------------------------------------------------------------------------------------
-// Tail of the V-cycle in one workgroup.  Same formulas, same per-row summation order as the per-level
-// kernels (k_jac_first / fused sweep / residual / restriction / prolongation): the result is bit-identical,
-// only ~100 dependent 3-5 us kernels per cycle collapse into one launch.
-// ------------------------------------------------------------------------------------------
-constexpr int MG_TAIL_ROWS = 8192;
-constexpr int MG_TAIL_THREADS = 1024;
-struct TailCsr { long long nrows; const long long* rowptr; const int* col; const double* val; };
-struct TailLevel {
-  TailCsr A, P, R;          // P, R: transfer to / from the next coarser level (unused on the last level)
-  const double* diag;
-  double *r, *z, *t;
-};
-
-__device__ inline double tail_row(const TailCsr& m, long long row, const double* __restrict__ x) {
-  double s = 0.0;
-  for (long long q = m.rowptr[row]; q < m.rowptr[row + 1]; ++q) s += m.val[q] * x[m.col[q]];
-  return s;
-}
-
-// sweeps of damped Jacobi on level L; returns with the iterate in `z` (ping-pong through `t`)
-__device__ inline void tail_smooth(const TailLevel& L, int sweeps, bool zero_guess, double omega, double*& z, double*& t) {
-  const long long n = L.A.nrows;
-  for (int s = 0; s < sweeps; ++s) {
-    if (s == 0 && zero_guess) {
-      for (long long i = threadIdx.x; i < n; i += MG_TAIL_THREADS) {
-        const double d = L.diag[i];
-        z[i] = d != 0.0 ? omega * L.r[i] / d : 0.0;
-      }
-    } else {
-      for (long long i = threadIdx.x; i < n; i += MG_TAIL_THREADS) {
-        const double ax = tail_row(L.A, i, z), d = L.diag[i], zi = z[i];
-        t[i] = d != 0.0 ? zi + omega * (L.r[i] - ax) / d : zi;
-      }
-      double* tmp = z; z = t; t = tmp;
-    }
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(MG_TAIL_THREADS) void k_mg_tail(const TailLevel* __restrict__ lv, int nl, int pre, int post,
-                                                              int coarse, double omega, double cscale) {
-  // per-level current (z, t) after ping-pong; small fixed bound on the number of tail levels
-  double* zc[8];
-  double* tc[8];
-  for (int l = 0; l < nl; ++l) { zc[l] = lv[l].z; tc[l] = lv[l].t; }
-  for (int l = 0; l + 1 < nl; ++l) {                       // down
-    const TailLevel& L = lv[l];
-    tail_smooth(L, pre, true, omega, zc[l], tc[l]);
-    for (long long i = threadIdx.x; i < L.A.nrows; i += MG_TAIL_THREADS) tc[l][i] = L.r[i] - tail_row(L.A, i, zc[l]);
-    __syncthreads();
-    for (long long i = threadIdx.x; i < L.R.nrows; i += MG_TAIL_THREADS) lv[l + 1].r[i] = tail_row(L.R, i, tc[l]);
-    __syncthreads();
-  }
-  tail_smooth(lv[nl - 1], coarse, true, omega, zc[nl - 1], tc[nl - 1]);
-  for (int l = nl - 2; l >= 0; --l) {                      // up
-    const TailLevel& L = lv[l];
-    for (long long i = threadIdx.x; i < L.A.nrows; i += MG_TAIL_THREADS) zc[l][i] = zc[l][i] + cscale * tail_row(L.P, i, zc[l + 1]);
-    __syncthreads();
-    tail_smooth(L, post, false, omega, zc[l], tc[l]);
-  }
-  // the caller reads the first tail level's correction from its `z` buffer
-  if (zc[0] != lv[0].z) {
-    for (long long i = threadIdx.x; i < lv[0].A.nrows; i += MG_TAIL_THREADS) lv[0].z[i] = zc[0][i];
-  }
-}
-
 int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
   mxg_ctx* c = mg->ctx;
   mxg_csr* A = mg->A[l];
@@ -291,12 +219,6 @@ int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
 
 int mg_cycle(mxg_mg* mg, int l) {
   mxg_ctx* c = mg->ctx;
-  if (l == mg->tail) {
-    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(MG_TAIL_THREADS), 0, c->stream, (const TailLevel*)mg->d_tail, mg->nlevels - l,
-                       mg->pre, mg->post, mg->coarse, mg->omega, mg->cscale);
-    MXG_HIP(hipGetLastError());
-    return 0;
-  }
   if (l == mg->nlevels - 1) return mg_smooth(mg, l, mg->coarse, true);
   const long long n = mg->A[l]->nrows;
   const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
@@ -349,24 +271,6 @@ extern "C" int mxg_mg_create(mxg_ctx* c, int nlevels, mxg_csr* const* A, mxg_csr
     MXG_TRY(mxg_mv_create(c, A[l]->nrows, 1, 0, &t));
     mg->r.push_back(r); mg->z.push_back(z); mg->t.push_back(t);
   }
-  // tail: the trailing levels with at most MG_TAIL_ROWS rows (never the finest level; at most 8 levels)
-  static const bool use_tail = !(getenv("MXG_MG_TAIL") && atoi(getenv("MXG_MG_TAIL")) == 0);
-  int tail = nlevels;
-  while (tail > 1 && A[tail - 1]->nrows <= MG_TAIL_ROWS && nlevels - (tail - 1) <= 8) --tail;
-  if (use_tail && tail < nlevels && tail >= 1) {
-    std::vector<TailLevel> tl((size_t)(nlevels - tail));
-    auto csr = [](const mxg_csr* m) { TailCsr t; t.nrows = m->nrows; t.rowptr = (const long long*)m->d_rowptr; t.col = m->d_colidx; t.val = m->d_vals; return t; };
-    for (int l = tail; l < nlevels; ++l) {
-      TailLevel& t = tl[(size_t)(l - tail)];
-      t.A = csr(mg->A[l]);
-      if (l + 1 < nlevels) { t.P = csr(mg->P[l]); t.R = csr(mg->R[l]); } else { t.P = TailCsr{0, nullptr, nullptr, nullptr}; t.R = t.P; }
-      t.diag = mg->A[l]->d_diag;
-      t.r = mg->r[l]->colptr(0); t.z = mg->z[l]->colptr(0); t.t = mg->t[l]->colptr(0);
-    }
-    MXG_HIP(hipMalloc(&mg->d_tail, sizeof(TailLevel) * tl.size()));
-    MXG_HIP(hipMemcpy(mg->d_tail, tl.data(), sizeof(TailLevel) * tl.size(), hipMemcpyHostToDevice));
-    mg->tail = tail;
-  }
   *out = mg;
   return 0;
 }
@@ -376,7 +280,6 @@ extern "C" int mxg_mg_destroy(mxg_mg* mg) {
   for (auto* v : mg->r) mxg_mv_destroy(v);
   for (auto* v : mg->z) mxg_mv_destroy(v);
   for (auto* v : mg->t) mxg_mv_destroy(v);
-  if (mg->d_tail) hipFree(mg->d_tail);
   delete mg;
   return 0;
 }
