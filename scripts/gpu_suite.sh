@@ -16,6 +16,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$TAG -- python $ROOT/bench.py --steps 50 --warmup 5 --eig-n 0 --cpu-seconds 0 --no-compressed > $OUT/prof_stats_$TAG.log 2>&1
 rc=$?; echo "stats rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_${ctr}_$TAG -- python $ROOT/bench.py --steps 10 --warmup 2 --eig-n 0 --cpu-seconds 0 --no-compressed > $OUT/pmc_${ctr}_$TAG.log 2>&1
+  timeout -k 10 600 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_${ctr}_$TAG -- python $ROOT/bench.py --steps 10 --warmup 2 --eig-n 0 --cpu-seconds 0 > $OUT/pmc_${ctr}_$TAG.log 2>&1
   rc=$?; echo "pmc $ctr rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
 done

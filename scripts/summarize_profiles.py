@@ -29,14 +29,17 @@ for name, out in (("bench_%s.json" % tag, "bench.json"), ("pytest_gpu_%s.log" % 
         shutil.copy(p, os.path.join(dst, out))
 
 bench = json.load(open(os.path.join(dst, "bench.json"))) if os.path.exists(os.path.join(dst, "bench.json")) else None
-res = {}
+res, cs = {}, {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     f = first("pmc_%s_%s/**/*counter_collection.csv" % (ctr, tag))
     if not f:
         continue
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == ctr and "k_spmv_rowgather" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
+    vals = [float(r["Counter_Value"]) for r in rows if "k_spmv_rowgather" in r["Kernel_Name"]]
     res[ctr] = {"dispatches": len(vals), "mean_raw_KiB": sum(vals) / max(len(vals), 1)}
+    vcs = [float(r["Counter_Value"]) for r in rows if "k_spmv_cs" in r["Kernel_Name"]]
+    if vcs:
+        cs[ctr] = {"dispatches": len(vcs), "mean_raw_KiB": sum(vcs) / len(vcs)}
 if len(res) == 2 and bench:
     rd = res["FETCH_SIZE"]["mean_raw_KiB"] * 1024 * 2
     wr = res["WRITE_SIZE"]["mean_raw_KiB"] * 1024
@@ -46,6 +49,13 @@ if len(res) == 2 and bench:
                          "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; separate --pmc passes")
     res["hbm_bytes_per_launch"] = {"read_corrected_x2": rd, "write": wr, "total": rd + wr, "algorithmic": alg,
                                    "ratio": (rd + wr) / alg}
+    if len(cs) == 2 and bench.get("compressed_stream", {}).get("bytes_moved_per_launch"):
+        crd, cwr = cs["FETCH_SIZE"]["mean_raw_KiB"] * 1024 * 2, cs["WRITE_SIZE"]["mean_raw_KiB"] * 1024
+        model = bench["compressed_stream"]["bytes_moved_per_launch"]
+        res["compressed_stream_kernel"] = {"FETCH_SIZE": cs["FETCH_SIZE"], "WRITE_SIZE": cs["WRITE_SIZE"],
+                                           "read_corrected_x2": crd, "write": cwr, "total": crd + cwr,
+                                           "modelled_bytes_moved": model, "ratio_to_model": (crd + cwr) / model,
+                                           "ratio_to_csr_formula": (crd + cwr) / alg}
     json.dump(res, open(os.path.join(dst, "hbm_counters.json"), "w"), indent=1)
     print(json.dumps(res["hbm_bytes_per_launch"]))
 print("wrote", sorted(os.listdir(dst)))
