@@ -67,3 +67,43 @@ def test_full_size_eigenpairs_against_the_analytic_cavity(ctx, sim256):
     assert abs(k2[1] - k2[2]) / te111 < 1e-8                    # the degenerate pair
     assert max(r["residual"] for r in res) < 1e-4 and max(r["divergence"] for r in res) < 1e-6   # as printed by checkEigensolution
     solver.close()
+
+
+def test_config3_cylinder_full_size_bit_exact(ctx, built):
+    """BASELINE config 3 (curved PEC cylinder, periodic z, 256^3: 25.6 M rows with irregular wall rows):
+    the whole product against the oracle's serial row loop, CSR and compressed stream."""
+    sim = mx.Sim(N, origin=(-0.5,) * 3, size=(1.0,) * 3, pec_shape="cylinder(0.4;0,0,1;0,0,0)")
+    A = sim.to_device(ctx, "vecLapl", shift=SHIFT)
+    host = sim.op("vecLapl", shift=SHIFT)
+    assert int(np.diff(host.indptr).max()) > 7                   # wall rows are wider than the 7-point bulk
+    x = np.random.default_rng(3).uniform(-1, 1, A.ncols)
+    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, A.nrows, 1)
+    A.apply(X, Y)
+    want = cref.spmv(host, x)
+    assert np.array_equal(Y.to_numpy()[:, 0], want)
+    A.compress()
+    A.apply(X, Y)
+    assert np.array_equal(Y.to_numpy()[:, 0], want)
+    sim.close()
+
+
+def test_config5_dielectric_block_of_8_bit_exact(ctx, built):
+    """BASELINE config 5 operator (eps = 10 sphere in a PEC sphere, octant box, FIT inverse permittivity) at
+    128^3 with a block of 8 right-hand sides: SpMM bit for bit against the serial row loop."""
+    sim = mx.Sim(128, origin=(0.0,) * 3, size=(0.5,) * 3, lower=("pmc", "pmc", "pec"), upper=("pec",) * 3,
+                 pec_shape="sphere(0.49;0,0,0)", dielectrics=[(10.0, "sphere(0.37;0,0,0)")])
+    A = sim.to_device(ctx, "vecLapl", shift=0.5)
+    host = sim.op("vecLapl", shift=0.5)
+    assert abs(host - host.T).max() > 1e-3                        # the FIT inverse permittivity is not symmetric
+    x = np.random.default_rng(5).uniform(-1, 1, (A.ncols, 8))
+    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, A.nrows, 8)
+    A.apply(X, Y)
+    got = Y.to_numpy()
+    for j in range(8):
+        assert np.array_equal(got[:, j], cref.spmv(host, x[:, j])), j
+    A.compress()
+    A.apply(X, Y)
+    got = Y.to_numpy()
+    for j in (0, 7):
+        assert np.array_equal(got[:, j], cref.spmv(host, x[:, j])), j
+    sim.close()
