@@ -4,11 +4,11 @@
 // reference's lookup order: body line `name = value` first, then the tag attribute, then the
 // default (src/MxUtil.cpp:266-315).
 //
-// In scope: 3-D, Grid, BoundaryConditions, PEC and lossless Dielectric blocks with
-// Cylinder / Sphere / Slab / HalfSpace / ShapeIntersection and the generic transforms, Eigensolver /
+// In scope: 3-D, Grid, BoundaryConditions, PEC and Dielectric blocks (loss tangent included)
+// with every shape tag of src/MxProblem.cpp:8-17 (Ellipsoid, Sphere, Cylinder, Torus, Cone, Slab, HalfSpace,
+// ShapeSubtract / Intersection / Union / Mirror / Repeat) and the generic transforms, Eigensolver /
 // LinearSolver / Preconditioner (phase shifts and loss tangents select the complex solver).  Mu / PML
-// blocks and the remaining shape tags are
-// rejected with a message instead of being ignored (a wrong answer would be silent otherwise).
+// blocks are rejected with a message instead of being ignored (a wrong answer would be silent otherwise).
 //
 // Deviation: the reference runs the solve inside the constructor and leaves solve() empty
 // (src/MxProblem.cpp:160-175,694); here the constructor parses and assembles, solve() solves.
@@ -420,6 +420,14 @@ class MxProblem {
     }
   }
 
+  // the shape blocks nested in a composite shape, in document order (Translate/Rotate/... are transforms of the composite)
+  std::vector<size_t> childShapes(XMLNode const& node) {
+    std::vector<size_t> out;
+    for (int i = 0; i < node.numChildren(); ++i)
+      if (isShapeTag(node.getChild(i).getTag())) out.push_back(getShape(node.getChild(i)));
+    return out;
+  }
+
   size_t getShape(XMLNode const& node) {   // src/MxProblem.cpp:277-384
     using MxUtil::XML::getAttr;
     const std::string tag = node.getTag();
@@ -445,16 +453,52 @@ class MxProblem {
       transforms(*shape, node);
     } else if (tag == "ShapeIntersection") {                             // src/MxProblem.cpp:316-326
       auto tmp = std::make_shared<mx::ShapeIntersection>();
-      for (int i = 0; i < node.numChildren(); ++i) {
-        if (!isShapeTag(node.getChild(i).getTag())) continue;            // Translate/Rotate/... handled below
-        const size_t indx = getShape(node.getChild(i));
-        tmp->add(shapes[indx]);
-      }
+      for (size_t indx : childShapes(node)) tmp->add(shapes[indx]);
       shape = tmp;
       transforms(*shape, node);
+    } else if (tag == "Ellipsoid") {                                     // src/MxEllipsoid.hpp:54-62
+      getAttr("name", node);
+      shape = std::make_shared<mx::Ellipsoid>(mxdetail::vec3(getAttr("axes", node)), zero);
+      transforms(*shape, node);
+    } else if (tag == "Torus") {                                         // src/MxTorus.hpp:69-82
+      getAttr("name", node);
+      const double R = atof(getAttr("major radius", node).c_str()), r = atof(getAttr("minor radius", node).c_str());
+      shape = std::make_shared<mx::Torus>(R, r, mxdetail::vec3(getAttr("axis", node)), zero);
+      transforms(*shape, node);
+    } else if (tag == "Cone") {                                          // src/MxCone.hpp:64-73
+      getAttr("name", node);
+      const double angle = atof(getAttr("angle", node).c_str());
+      shape = std::make_shared<mx::Cone>(angle, mxdetail::vec3(getAttr("axis", node)), zero);
+      transforms(*shape, node);
+    } else if (tag == "ShapeUnion") {                                    // src/MxProblem.cpp:327-336
+      auto tmp = std::make_shared<mx::ShapeUnion>();
+      for (size_t indx : childShapes(node)) tmp->add(shapes[indx]);
+      shape = tmp;
+      transforms(*shape, node);
+    } else if (tag == "ShapeSubtract") {                                 // src/MxProblem.cpp:297-314: base, then the shape removed
+      const std::vector<size_t> kids = childShapes(node);
+      if (kids.size() != 2) throw std::runtime_error("'ShapeSubtract' should have exactly 2 shape subobjects.");
+      auto tmp = std::make_shared<mx::ShapeSubtract>();
+      tmp->setBaseShape(shapes[kids[0]]);
+      tmp->subtractShape(shapes[kids[1]]);
+      shape = tmp;
+      transforms(*shape, node);
+    } else if (tag == "ShapeMirror") {                                   // src/MxProblem.cpp:337-353
+      const mx::Vec3 n = mxdetail::vec3(getAttr("normal", node)), p = mxdetail::vec3(getAttr("point in plane", node));
+      const std::vector<size_t> kids = childShapes(node);
+      if (kids.size() != 1) throw std::runtime_error("ShapeMirror XML block must contain one shape block.");
+      shape = std::make_shared<mx::ShapeMirror>(shapes[kids[0]], n, p);
+      transforms(*shape, node);
+    } else if (tag == "ShapeRepeat") {                                   // src/MxProblem.cpp:354-375
+      const mx::Vec3 o = mxdetail::vec3(getAttr("origin", node)), dir = mxdetail::vec3(getAttr("direction", node));
+      const double step = atof(getAttr("step", node).c_str());
+      const int numPos = atoi(getAttr("pos steps", node).c_str()), numNeg = atoi(getAttr("neg steps", node).c_str());
+      const std::vector<size_t> kids = childShapes(node);
+      if (kids.size() != 1) throw std::runtime_error("ShapeRepeat XML block must contain one shape block.");
+      shape = std::make_shared<mx::ShapeRepeat>(shapes[kids[0]], o, dir, step, numPos, numNeg);
+      transforms(*shape, node);
     } else {
-      throw std::runtime_error("MxProblem<3>::getShape: shape tag '" + tag + "' is not built in this round "
-                               "(available: Sphere, Cylinder, Slab, HalfSpace, ShapeIntersection).");
+      throw std::runtime_error("MxProblem<3>::getShape: did not understand shape tag '" + tag + "'.");
     }
     shapes.push_back(shape);
     return shapes.size() - 1;

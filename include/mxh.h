@@ -29,6 +29,10 @@ const char* mxh_last_error(void);
  *   pec_shape:   NULL/"" for none, else primitives joined by '&' (ShapeIntersection):
  *                  cylinder(r; ax,ay,az; x,y,z)   slab(t; nx,ny,nz; x,y,z)
  *                  sphere(r; x,y,z)               halfspace(nx,ny,nz; x,y,z)
+ *                  ellipsoid(a,b,c; x,y,z)        torus(R; r; ax,ay,az; x,y,z)
+ *                  cone(angle; ax,ay,az; x,y,z)   (vertex at x,y,z)
+ *                unions, differences, mirrors, repeats and transformed shapes come in through a deck
+ *                (mxh_problem_parse, all shape tags of src/MxProblem.cpp:8-17)
  *   strict:      1 = reference behaviour incl. the periodic-wrap quirk of
  *                MxYeeFitEField::getCompFactor, 0 = wrap-corrected */
 int mxh_sim_create(const int n[3], const double origin[3], const double size[3],

@@ -1,6 +1,10 @@
 // See mx_geometry.hpp for the reference lines each routine follows.
 #include "mx_geometry.hpp"
 
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
 namespace mx {
 
 Mat3 matmul(const Mat3& x, const Mat3& y) {
@@ -119,6 +123,100 @@ Slab::Slab(double l, const Vec3& normal, const Vec3& mid) {  // src/MxSlab.hpp:6
   slab_.add(std::make_shared<HalfSpace>((-0.5 * l) * n, n));
   slab_.add(std::make_shared<HalfSpace>((0.5 * l) * n, -1.0 * n));
   translate(mid);
+}
+
+
+static Mat3 complementProjector(const Vec3& a) {
+  Mat3 P = Mat3::eye();
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) P.a[i][j] -= a[i] * a[j];
+  return P;
+}
+static Vec3 unit(const Vec3& v) {
+  const double nn = norm(v);
+  return Vec3(v[0] / nn, v[1] / nn, v[2] / nn);
+}
+
+Ellipsoid::Ellipsoid(const Vec3& axes, const Vec3& location)
+    : ia_(1.0 / (axes[0] * axes[0]), 1.0 / (axes[1] * axes[1]), 1.0 / (axes[2] * axes[2])) { translate(location); }
+
+Torus::Torus(double R, double r, const Vec3& axis, const Vec3& location) : R_(R), r2_(r * r), a_(unit(axis)) {
+  P_ = complementProjector(a_);
+  translate(location);
+}
+double Torus::localFunc(const Vec3& q) const {
+  const double nrm = norm(P_.mul(q)), ax = dot(a_, q);
+  return r2_ - (R_ - nrm) * (R_ - nrm) - ax * ax;
+}
+Vec3 Torus::localGrad(const Vec3& q) const {
+  const double nrm = norm(P_.mul(q)), ax = dot(a_, q), f = 1.0 - R_ / nrm;
+  double g[3];   // ((1 - R/|Pq|) * P) * q: the scalar scales the projector first (src/MxTorus.hpp:36)
+  for (int i = 0; i < 3; ++i) g[i] = (f * P_.a[i][0]) * q[0] + (f * P_.a[i][1]) * q[1] + (f * P_.a[i][2]) * q[2];
+  return Vec3(2.0 * (g[0] - ax * a_[0]), 2.0 * (g[1] - ax * a_[1]), 2.0 * (g[2] - ax * a_[2]));
+}
+
+Cone::Cone(double angle, const Vec3& axis, const Vec3& vertex) : tan_(std::tan(angle)), a_(unit(axis)) {
+  P_ = complementProjector(a_);
+  translate(vertex);
+}
+double Cone::localFunc(const Vec3& q) const {
+  const double t = tan_ * dot(a_, q);
+  return t * t - dot(q, P_.mul(q));
+}
+Vec3 Cone::localGrad(const Vec3& q) const {
+  const Vec3 pq = P_.mul(q);
+  const double c = tan_ * tan_ * dot(a_, q);
+  return Vec3(2.0 * (c * a_[0] - pq[0]), 2.0 * (c * a_[1] - pq[1]), 2.0 * (c * a_[2] - pq[2]));
+}
+
+double ShapeUnion::localFunc(const Vec3& q) const {
+  double fmax = -std::numeric_limits<double>::max();
+  for (const auto& s : shapes_) {
+    const double f = s->func(q);
+    if (f > fmax) fmax = f;
+  }
+  return fmax;
+}
+Vec3 ShapeUnion::localGrad(const Vec3& q) const {
+  double fmax = -std::numeric_limits<double>::max();
+  const Shape* pick = nullptr;
+  for (const auto& s : shapes_) {
+    const double f = s->func(q);
+    if (f > fmax) { fmax = f; pick = s.get(); }
+  }
+  return pick->gradFunc(q);
+}
+
+double ShapeSubtract::localFunc(const Vec3& q) const {
+  const double fBase = base_->func(q), fRm = rm_.func(q);
+  const bool inBase = fBase > 0, inRm = fRm < 0;
+  if (inRm && inBase) return fRm;
+  if (!inRm && !inBase) return fBase;
+  return fBase < fRm ? fBase : fRm;
+}
+Vec3 ShapeSubtract::localGrad(const Vec3& q) const {
+  const double fBase = base_->func(q), fRm = rm_.func(q);
+  const bool inBase = fBase > 0, inRm = fRm < 0;
+  if (inRm && inBase) return rm_.gradFunc(q);
+  if (!inRm && !inBase) return base_->gradFunc(q);
+  return fBase < fRm ? base_->gradFunc(q) : rm_.gradFunc(q);
+}
+
+ShapeMirror::ShapeMirror(std::shared_ptr<const Shape> shape, const Vec3& normal, const Vec3& p) : shape_(std::move(shape)) {
+  const Vec3 n = unit(normal);
+  plane_ = std::make_shared<HalfSpace>(p, n);
+  std::shared_ptr<Shape> m = shape_->clone();
+  m->reflect(n, p);
+  mirror_ = m;
+}
+
+ShapeRepeat::ShapeRepeat(std::shared_ptr<const Shape> shape, const Vec3& origin, const Vec3& direction, double step,
+                         int numPos, int numNeg)
+    : shape_(std::move(shape)), o_(origin), dir_(unit(direction)), s_(step), np_(numPos), nn_(-numNeg) {}
+Vec3 ShapeRepeat::fold(const Vec3& p) const {
+  const double slabPt = dot(p - o_, dir_) / s_ + 0.5;
+  const double k = slabPt >= 0.0 ? std::min(std::floor(slabPt), np_) : std::max(std::floor(slabPt), nn_);
+  const double sk = s_ * k;
+  return Vec3(p[0] - sk * dir_[0], p[1] - sk * dir_[1], p[2] - sk * dir_[2]);
 }
 
 Vec3 rootFind(const Shape& shape, const Vec3& p1, const Vec3& p2, double tol) {

@@ -69,6 +69,8 @@ class Shape {
   void reflect(const Vec3& normal, const Vec3& pointInPlane);
   void invert() { sign_ *= -1.0; }
   const Vec3& translation() const { return b_; }
+  // deep copy including the transform (MxShape::clone); members of composite shapes are shared (immutable)
+  virtual std::shared_ptr<Shape> clone() const = 0;
 
  protected:
   virtual double localFunc(const Vec3& q) const = 0;
@@ -83,6 +85,7 @@ class Shape {
 class HalfSpace : public Shape {
  public:
   HalfSpace(const Vec3& pointInPlane, const Vec3& normal);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<HalfSpace>(*this); }
  protected:
   double localFunc(const Vec3& q) const override { return dot(n_, q); }
   Vec3 localGrad(const Vec3&) const override { return n_; }
@@ -93,6 +96,7 @@ class HalfSpace : public Shape {
 class Cylinder : public Shape {
  public:
   Cylinder(double radius, const Vec3& axis, const Vec3& location);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<Cylinder>(*this); }
  protected:
   double localFunc(const Vec3& q) const override { return r2_ - dot(q, P_.mul(q)); }
   Vec3 localGrad(const Vec3& q) const override { return -2.0 * P_.mul(q); }
@@ -104,6 +108,7 @@ class Cylinder : public Shape {
 class Sphere : public Shape {
  public:
   Sphere(double radius, const Vec3& location);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<Sphere>(*this); }
  protected:
   double localFunc(const Vec3& q) const override { return 1.0 - dot(q, q) / r2_; }
   Vec3 localGrad(const Vec3& q) const override {   // -2.0 * p / r2, left to right
@@ -117,6 +122,7 @@ class ShapeIntersection : public Shape {
  public:
   ShapeIntersection() {}
   void add(std::shared_ptr<const Shape> s) { shapes_.push_back(std::move(s)); }
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<ShapeIntersection>(*this); }
  protected:
   double localFunc(const Vec3& q) const override;
   Vec3 localGrad(const Vec3& q) const override;
@@ -127,11 +133,109 @@ class ShapeIntersection : public Shape {
 class Slab : public Shape {
  public:
   Slab(double thickness, const Vec3& normal, const Vec3& midplanePoint);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<Slab>(*this); }
  protected:
   double localFunc(const Vec3& q) const override { return slab_.func(q); }
   Vec3 localGrad(const Vec3& q) const override { return slab_.gradFunc(q); }
  private:
   ShapeIntersection slab_;
+};
+
+// src/MxEllipsoid.hpp:33-35,46-48: 1 - sum p_i^2 / a_i^2
+class Ellipsoid : public Shape {
+ public:
+  Ellipsoid(const Vec3& axes, const Vec3& location);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<Ellipsoid>(*this); }
+ protected:
+  double localFunc(const Vec3& q) const override {
+    return 1.0 - (q[0] * (ia_[0] * q[0]) + q[1] * (ia_[1] * q[1]) + q[2] * (ia_[2] * q[2]));
+  }
+  Vec3 localGrad(const Vec3& q) const override { return Vec3((-2.0 * ia_[0]) * q[0], (-2.0 * ia_[1]) * q[1], (-2.0 * ia_[2]) * q[2]); }
+ private:
+  Vec3 ia_;
+};
+
+// src/MxTorus.hpp:31-37: r^2 - (R - |P p|)^2 - (a.p)^2
+class Torus : public Shape {
+ public:
+  Torus(double majorRadius, double minorRadius, const Vec3& axis, const Vec3& location);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<Torus>(*this); }
+ protected:
+  double localFunc(const Vec3& q) const override;
+  Vec3 localGrad(const Vec3& q) const override;
+ private:
+  double R_, r2_;
+  Vec3 a_;
+  Mat3 P_;
+};
+
+// src/MxCone.hpp:31-37: (tan(theta) a.p)^2 - p.(P p), vertex at the translation point (double cone)
+class Cone : public Shape {
+ public:
+  Cone(double angle, const Vec3& axis, const Vec3& vertex);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<Cone>(*this); }
+ protected:
+  double localFunc(const Vec3& q) const override;
+  Vec3 localGrad(const Vec3& q) const override;
+ private:
+  double tan_;
+  Vec3 a_;
+  Mat3 P_;
+};
+
+// src/MxShapeUnion.hpp:68-83,136-154: max of the members, gradient of the first member attaining it
+class ShapeUnion : public Shape {
+ public:
+  ShapeUnion() {}
+  void add(std::shared_ptr<const Shape> s) { shapes_.push_back(std::move(s)); }
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<ShapeUnion>(*this); }
+ protected:
+  double localFunc(const Vec3& q) const override;
+  Vec3 localGrad(const Vec3& q) const override;
+ private:
+  std::vector<std::shared_ptr<const Shape>> shapes_;
+};
+
+// src/MxShapeSubtract.hpp:73-90,157-175: base minus the (inverted) union of the subtracted shapes
+class ShapeSubtract : public Shape {
+ public:
+  ShapeSubtract() { rm_.invert(); }
+  void setBaseShape(std::shared_ptr<const Shape> s) { base_ = std::move(s); }
+  void subtractShape(std::shared_ptr<const Shape> s) { rm_.add(std::move(s)); }
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<ShapeSubtract>(*this); }
+ protected:
+  double localFunc(const Vec3& q) const override;
+  Vec3 localGrad(const Vec3& q) const override;
+ private:
+  std::shared_ptr<const Shape> base_;
+  ShapeUnion rm_;
+};
+
+// src/MxShapeMirror.hpp:86-116,156-170: the shape on the positive side of the plane, its mirror image on the other
+class ShapeMirror : public Shape {
+ public:
+  ShapeMirror(std::shared_ptr<const Shape> shape, const Vec3& normal, const Vec3& pointInPlane);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<ShapeMirror>(*this); }
+ protected:
+  double localFunc(const Vec3& q) const override { return plane_->func(q) > 0.0 ? shape_->func(q) : mirror_->func(q); }
+  Vec3 localGrad(const Vec3& q) const override { return plane_->func(q) > 0.0 ? shape_->gradFunc(q) : mirror_->gradFunc(q); }
+ private:
+  std::shared_ptr<const Shape> shape_, mirror_, plane_;
+};
+
+// src/MxShapeRepeat.hpp:86-120,140-150: copies of the shape at origin + i * step * direction, i = -numNeg..numPos
+class ShapeRepeat : public Shape {
+ public:
+  ShapeRepeat(std::shared_ptr<const Shape> shape, const Vec3& origin, const Vec3& direction, double step, int numPos, int numNeg);
+  std::shared_ptr<Shape> clone() const override { return std::make_shared<ShapeRepeat>(*this); }
+ protected:
+  double localFunc(const Vec3& q) const override { return shape_->func(fold(q)); }
+  Vec3 localGrad(const Vec3& q) const override { return shape_->gradFunc(fold(q)); }
+ private:
+  Vec3 fold(const Vec3& p) const;
+  std::shared_ptr<const Shape> shape_;
+  Vec3 o_, dir_;
+  double s_, np_, nn_;
 };
 
 Vec3 rootFind(const Shape& shape, const Vec3& p1, const Vec3& p2, double tol = 1.e-12);

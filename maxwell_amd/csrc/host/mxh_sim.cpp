@@ -46,6 +46,12 @@ std::shared_ptr<const mx::Shape> parsePrimitive(const std::string& tok) {
     return std::make_shared<mx::Sphere>(a[0], Vec3(a[1], a[2], a[3]));
   if (name == "halfspace" && a.size() == 6)
     return std::make_shared<mx::HalfSpace>(Vec3(a[3], a[4], a[5]), Vec3(a[0], a[1], a[2]));
+  if (name == "ellipsoid" && a.size() == 6)
+    return std::make_shared<mx::Ellipsoid>(Vec3(a[0], a[1], a[2]), Vec3(a[3], a[4], a[5]));
+  if (name == "torus" && a.size() == 8)
+    return std::make_shared<mx::Torus>(a[0], a[1], Vec3(a[2], a[3], a[4]), Vec3(a[5], a[6], a[7]));
+  if (name == "cone" && a.size() == 7)
+    return std::make_shared<mx::Cone>(a[0], Vec3(a[1], a[2], a[3]), Vec3(a[4], a[5], a[6]));
   throw std::runtime_error("unknown shape or wrong argument count in '" + tok + "'");
 }
 

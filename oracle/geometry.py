@@ -6,7 +6,9 @@ Dey-Mittra fractions (and therefore the assembled pencil):
   shapes      src/MxShape.hpp:145-172 (func = sign * _func(Ainv p - Ainv b)),
               src/MxCylinder.hpp:34-40, src/MxHalfSpace.hpp:31-33,
               src/MxSlab.hpp:95-100,140-146, src/MxSphere.hpp:31-33,
-              src/MxShapeIntersection.hpp:122-136,186-206
+              src/MxShapeIntersection.hpp:122-136,186-206, src/MxEllipsoid.hpp, src/MxTorus.hpp,
+              src/MxCone.hpp, src/MxShapeUnion.hpp, src/MxShapeSubtract.hpp, src/MxShapeMirror.hpp,
+              src/MxShapeRepeat.hpp
   sign()      src/MxUtil.hpp:26,44-49 (dEps = 0)
   rootFind    src/MxUtil.hpp:297-362 (safeguarded Newton, maxiter forced 500)
   segment     src/MxSegment.cpp:21-42
@@ -246,6 +248,226 @@ class Slab(Shape):
 
     def _grad1(self, q):
         return self.slab.grad1(q)
+
+
+class Ellipsoid(Shape):
+    """src/MxEllipsoid.hpp:33-35,46-48: _func(q) = 1 - sum q_i^2 / a_i^2."""
+
+    def __init__(self, axes, location):
+        super().__init__()
+        self.ia = [1.0 / (float(a) * float(a)) for a in axes]
+        self.translate(location)
+
+    def _func(self, q):
+        ia = self.ia
+        return 1.0 - (q[..., 0] * (ia[0] * q[..., 0]) + q[..., 1] * (ia[1] * q[..., 1]) + q[..., 2] * (ia[2] * q[..., 2]))
+
+    def _func1(self, q):
+        ia = self.ia
+        return 1.0 - (q[0] * (ia[0] * q[0]) + q[1] * (ia[1] * q[1]) + q[2] * (ia[2] * q[2]))
+
+    def _grad1(self, q):
+        ia = self.ia
+        return ((-2.0 * ia[0]) * q[0], (-2.0 * ia[1]) * q[1], (-2.0 * ia[2]) * q[2])
+
+
+class _Axial(Shape):
+    """Shared by Torus and Cone: unit axis a and the projector P = I - a a^T."""
+
+    def _set_axis(self, axis):
+        nn = _norm3(axis)
+        self.a = [float(axis[0]) / nn, float(axis[1]) / nn, float(axis[2]) / nn]
+        a = self.a
+        self.P = [[(1.0 if i == j else 0.0) - a[i] * a[j] for j in range(3)] for i in range(3)]
+
+    def _Pq(self, q0, q1, q2):
+        P = self.P
+        return (P[0][0] * q0 + P[0][1] * q1 + P[0][2] * q2,
+                P[1][0] * q0 + P[1][1] * q1 + P[1][2] * q2,
+                P[2][0] * q0 + P[2][1] * q1 + P[2][2] * q2)
+
+    def _aq(self, q0, q1, q2):
+        a = self.a
+        return a[0] * q0 + a[1] * q1 + a[2] * q2
+
+
+class Torus(_Axial):
+    """src/MxTorus.hpp:31-37: _func(q) = r^2 - (R - |P q|)^2 - (a.q)^2."""
+
+    def __init__(self, major_radius, minor_radius, axis, location):
+        super().__init__()
+        self.R = float(major_radius)
+        self.r2 = float(minor_radius) * float(minor_radius)
+        self._set_axis(axis)
+        self.translate(location)
+
+    def _func(self, q):
+        q0, q1, q2 = q[..., 0], q[..., 1], q[..., 2]
+        p = self._Pq(q0, q1, q2)
+        nrm = np.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2])
+        ax = self._aq(q0, q1, q2)
+        return self.r2 - (self.R - nrm) * (self.R - nrm) - ax * ax
+
+    def _func1(self, q):
+        p = self._Pq(q[0], q[1], q[2])
+        nrm = math.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2])
+        ax = self._aq(q[0], q[1], q[2])
+        return self.r2 - (self.R - nrm) * (self.R - nrm) - ax * ax
+
+    def _grad1(self, q):
+        p = self._Pq(q[0], q[1], q[2])
+        nrm = math.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2])
+        ax = self._aq(q[0], q[1], q[2])
+        f = 1.0 - (self.R / nrm if nrm != 0.0 else float("inf"))
+        a, P = self.a, self.P
+        # ((1 - R/|Pq|) * P) * q: the scalar scales the projector first (src/MxTorus.hpp:36)
+        g = [(f * P[i][0]) * q[0] + (f * P[i][1]) * q[1] + (f * P[i][2]) * q[2] for i in range(3)]
+        return (2.0 * (g[0] - ax * a[0]), 2.0 * (g[1] - ax * a[1]), 2.0 * (g[2] - ax * a[2]))
+
+
+class Cone(_Axial):
+    """src/MxCone.hpp:31-37: _func(q) = (tan(theta) a.q)^2 - q.(P q); a double cone with its vertex at `vertex`."""
+
+    def __init__(self, angle, axis, vertex):
+        super().__init__()
+        self.tan = math.tan(float(angle))
+        self._set_axis(axis)
+        self.translate(vertex)
+
+    def _func(self, q):
+        q0, q1, q2 = q[..., 0], q[..., 1], q[..., 2]
+        p = self._Pq(q0, q1, q2)
+        t = self.tan * self._aq(q0, q1, q2)
+        return t * t - (q0 * p[0] + q1 * p[1] + q2 * p[2])
+
+    def _func1(self, q):
+        p = self._Pq(q[0], q[1], q[2])
+        t = self.tan * self._aq(q[0], q[1], q[2])
+        return t * t - (q[0] * p[0] + q[1] * p[1] + q[2] * p[2])
+
+    def _grad1(self, q):
+        p = self._Pq(q[0], q[1], q[2])
+        c = self.tan * self.tan * self._aq(q[0], q[1], q[2])
+        a = self.a
+        return (2.0 * (c * a[0] - p[0]), 2.0 * (c * a[1] - p[1]), 2.0 * (c * a[2] - p[2]))
+
+
+class Union(Shape):
+    """src/MxShapeUnion.hpp:68-83 (max of members), 136-154 (gradient of the first member attaining the max)."""
+
+    def __init__(self, shapes=()):
+        super().__init__()
+        self.shapes = list(shapes)
+
+    def _func(self, q):
+        f = self.shapes[0].func(q)
+        for s in self.shapes[1:]:
+            f = np.maximum(f, s.func(q))
+        return f
+
+    def _func1(self, q):
+        fmax = -float("inf")
+        for s in self.shapes:
+            f = s.func1(q)
+            if f > fmax:
+                fmax = f
+        return fmax
+
+    def _grad1(self, q):
+        fmax = -float("inf")
+        pick = None
+        for s in self.shapes:
+            f = s.func1(q)
+            if f > fmax:
+                fmax = f
+                pick = s
+        return pick.grad1(q)
+
+
+class Subtract(Shape):
+    """src/MxShapeSubtract.hpp:73-90,157-175; the removed shapes form an inverted union."""
+
+    def __init__(self, base, removed):
+        super().__init__()
+        self.base = base
+        self.rm = Union(removed).invert()
+
+    def _func(self, q):
+        fb, fr = self.base.func(q), self.rm.func(q)
+        in_b, in_r = fb > 0, fr < 0
+        return np.where(in_r & in_b, fr, np.where(~in_r & ~in_b, fb, np.where(fb < fr, fb, fr)))
+
+    def _pick(self, q):
+        fb, fr = self.base.func1(q), self.rm.func1(q)
+        in_b, in_r = fb > 0, fr < 0
+        if in_r and in_b:
+            return fr, self.rm
+        if not in_r and not in_b:
+            return fb, self.base
+        return (fb, self.base) if fb < fr else (fr, self.rm)
+
+    def _func1(self, q):
+        return self._pick(q)[0]
+
+    def _grad1(self, q):
+        return self._pick(q)[1].grad1(q)
+
+
+class Mirror(Shape):
+    """src/MxShapeMirror.hpp:86-116,156-170: the shape where the half space (point, normal) is positive, its reflection elsewhere."""
+
+    def __init__(self, shape, normal, point=(0.0, 0.0, 0.0)):
+        import copy
+        super().__init__()
+        nn = _norm3(normal)
+        n = [float(normal[0]) / nn, float(normal[1]) / nn, float(normal[2]) / nn]
+        p = [float(x) for x in point]
+        self.shape = shape
+        self.plane = HalfSpace(p, n)
+        self.mirror = copy.deepcopy(shape).reflect(n, p)
+
+    def _func(self, q):
+        return np.where(self.plane.func(q) > 0.0, self.shape.func(q), self.mirror.func(q))
+
+    def _func1(self, q):
+        return self.shape.func1(q) if self.plane.func1(q) > 0.0 else self.mirror.func1(q)
+
+    def _grad1(self, q):
+        return self.shape.grad1(q) if self.plane.func1(q) > 0.0 else self.mirror.grad1(q)
+
+
+class Repeat(Shape):
+    """src/MxShapeRepeat.hpp:86-120,140-150: copies at origin + i * step * direction for i = -num_neg .. num_pos."""
+
+    def __init__(self, shape, origin, direction, step, num_pos, num_neg):
+        super().__init__()
+        nn = _norm3(direction)
+        self.dir = [float(direction[0]) / nn, float(direction[1]) / nn, float(direction[2]) / nn]
+        self.o = [float(x) for x in origin]
+        self.s, self.np_, self.nn_ = float(step), float(int(num_pos)), float(-int(num_neg))
+        self.shape = shape
+
+    def _fold1(self, p):
+        o, d = self.o, self.dir
+        slab = ((p[0] - o[0]) * d[0] + (p[1] - o[1]) * d[1] + (p[2] - o[2]) * d[2]) / self.s + 0.5
+        k = min(math.floor(slab), self.np_) if slab >= 0.0 else max(math.floor(slab), self.nn_)
+        sk = self.s * float(k)
+        return (p[0] - sk * d[0], p[1] - sk * d[1], p[2] - sk * d[2])
+
+    def _func(self, q):
+        o, d = self.o, self.dir
+        q0, q1, q2 = q[..., 0], q[..., 1], q[..., 2]
+        slab = ((q0 - o[0]) * d[0] + (q1 - o[1]) * d[1] + (q2 - o[2]) * d[2]) / self.s + 0.5
+        fl = np.floor(slab)
+        k = np.where(slab >= 0.0, np.minimum(fl, self.np_), np.maximum(fl, self.nn_))
+        sk = self.s * k
+        return self.shape.func(np.stack([q0 - sk * d[0], q1 - sk * d[1], q2 - sk * d[2]], axis=-1))
+
+    def _func1(self, q):
+        return self.shape.func1(self._fold1(q))
+
+    def _grad1(self, q):
+        return self.shape.grad1(self._fold1(q))
 
 
 def pillbox(radius=0.4, length=0.8):

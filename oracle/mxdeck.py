@@ -109,7 +109,34 @@ def make_shape(node):
     if tag == "ShapeIntersection":
         parts = [make_shape(c) for c in node if c.tag in SHAPE_TAGS]
         return transforms(geo.Intersection(parts), node)
-    raise ValueError("shape tag '%s' is not restated" % tag)
+    if tag == "Ellipsoid":
+        get_attr("name", node)
+        return transforms(geo.Ellipsoid(vec(get_attr("axes", node)), zero), node)
+    if tag == "Torus":
+        get_attr("name", node)
+        return transforms(geo.Torus(float(get_attr("major radius", node)), float(get_attr("minor radius", node)),
+                                    vec(get_attr("axis", node)), zero), node)
+    if tag == "Cone":
+        get_attr("name", node)
+        return transforms(geo.Cone(float(get_attr("angle", node)), vec(get_attr("axis", node)), zero), node)
+    parts = [make_shape(c) for c in node if c.tag in SHAPE_TAGS]
+    if tag == "ShapeUnion":
+        return transforms(geo.Union(parts), node)
+    if tag == "ShapeSubtract":                                    # src/MxProblem.cpp:297-314: base, then the shape removed
+        if len(parts) != 2:
+            raise ValueError("'ShapeSubtract' should have exactly 2 shape subobjects")
+        return transforms(geo.Subtract(parts[0], [parts[1]]), node)
+    if tag == "ShapeMirror":
+        if len(parts) != 1:
+            raise ValueError("ShapeMirror XML block must contain one shape block")
+        return transforms(geo.Mirror(parts[0], vec(get_attr("normal", node)), vec(get_attr("point in plane", node))), node)
+    if tag == "ShapeRepeat":
+        if len(parts) != 1:
+            raise ValueError("ShapeRepeat XML block must contain one shape block")
+        return transforms(geo.Repeat(parts[0], vec(get_attr("origin", node)), vec(get_attr("direction", node)),
+                                     float(get_attr("step", node)), int(get_attr("pos steps", node)),
+                                     int(get_attr("neg steps", node))), node)
+    raise ValueError("did not understand shape tag '%s'" % tag)
 
 
 class Deck:

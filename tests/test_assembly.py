@@ -78,6 +78,22 @@ def test_config3_curved_pec_cylinder_matches_oracle(built):
     assert rows.max() > 7 and (rows == 7).sum() > 0      # wall rows wider than the bulk stencil
 
 
+def test_ellipsoid_cone_torus_primitives_match_oracle(built):
+    """The remaining primitive level sets (src/MxEllipsoid.hpp:33-35, src/MxCone.hpp:31-37, src/MxTorus.hpp:31-37)
+    through the C ABI's shape tokens: an ellipsoidal PEC cavity clipped by a cone, with a dielectric torus inside
+    (cut faces, cut edges and the FIT inverse permittivity on a torus surface)."""
+    from oracle import geometry as geo
+    kw = dict(origin=(-0.52, -0.5, -0.49), size=(1.0, 1.0, 1.0), lower=("pec",) * 3, upper=("pec",) * 3)
+    pec = geo.Intersection([geo.Ellipsoid([0.45, 0.4, 0.35], [0.0, 0.01, 0.0]), geo.Cone(1.2, [0, 0.1, 1], [0.0, 0.0, -0.6])])
+    osim = yee.YeeSim(9, pec=pec, dielectrics=[(geo.Torus(0.2, 0.08, [0.1, 0, 1], [0.01, 0, 0.02]), 6.0 * np.eye(3), "ring")], **kw)
+    sim = mx.Sim(9, pec_shape="ellipsoid(0.45,0.4,0.35;0,0.01,0) & cone(1.2;0,0.1,1;0,0,-0.6)",
+                 dielectrics=[(6.0, "torus(0.2;0.08;0.1,0,1;0.01,0,0.02)")], **kw)
+    o = osim.wave_ops()
+    for name, ref in o.items():
+        assert _same(sim.op(name), ref), name
+    assert "invEps" in o and np.abs(o["invEps"].data - 1.0).max() > 0.5
+
+
 # ---- f3: FIT inverse permittivity (src/MxYeeFitInvEps.cpp), dielectrics on E / D / Psi ----------------
 
 def _all_ops_same(sim, o):

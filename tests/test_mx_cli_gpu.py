@@ -209,3 +209,34 @@ def test_lossy_dielectric_sphere_complex_frequencies(ctx):
     assert np.abs(got - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (got, want)
     q = got.real / np.abs(got.imag)     # k^2 ~ omega^2 (1 - i/Q): Q = 1 / (loss tangent x electric filling factor) >= 1000
     assert np.all(q > 1000) and np.all(q < 3000)
+
+
+def test_crab_cell_deck_composite_shapes(ctx):
+    """tests/golden/crabcell.mx (geometry after example/crabcav.py:42-66): Cone, Torus, Ellipsoid, ShapeSubtract /
+    Union / Mirror / Repeat through MxProblem -> MxSolver; the three-cell TM010-like passband against the sparse
+    shift-invert of the oracle-assembled pencil."""
+    name = os.path.join(GOLDEN, "crabcell.mx")
+    deck = mxdeck.load(name)
+    solver = mx.Problem(path=name).solver(ctx)
+    assert solver.solve() == 3
+    k2 = np.sort([solver.result(i)["k2"].real for i in range(3)])
+    want = _sparse_physical_modes(deck, 3)
+    assert np.abs(k2 - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (k2, want)
+    assert 60.0 < k2[0] < k2[2] < 75.0      # (2.405 / 0.36)^2 = 44.6 for the bare equator radius, raised by the cone walls
+
+
+def test_pillbox_with_tubes_deck_phase_advance(ctx):
+    """tests/golden/pillwtubes.mx (geometry after example/pillWTubes.py:91-104): ShapeUnion of a pillbox and a
+    corrugated tube (inverted tori), 2 pi / 3 Bloch phase advance per cell -> complex solver.  strict=False as for
+    every periodic deck."""
+    name = os.path.join(GOLDEN, "pillwtubes.mx")
+    deck = mxdeck.load(name)
+    prob = mx.Problem(path=name, strict=False)
+    assert prob.is_complex
+    solver = prob.solver(ctx)
+    assert solver.solve() == 2
+    res = [solver.result(i) for i in range(2)]
+    k2 = np.sort([r["k2"].real for r in res])
+    want = yee.mag_wave_modes(deck.sim(strict=False).wave_ops(), deck.params["eigensolver : shift"], 2)
+    assert np.abs(k2 - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (k2, want)
+    assert max(abs(r["k2"].imag) for r in res) < 1e-6 * np.abs(want).max()

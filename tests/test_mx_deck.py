@@ -14,8 +14,8 @@ from oracle import mxdeck
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 pytestmark = pytest.mark.usefixtures("built")
-DECKS = ["pillbox.mx", "vacuum.mx", "tilted_cavity.mx", "dsphmsph.mx"]
-COMPLEX_DECKS = ["fiber.mx"]
+DECKS = ["pillbox.mx", "vacuum.mx", "tilted_cavity.mx", "dsphmsph.mx", "crabcell.mx"]
+COMPLEX_DECKS = ["fiber.mx", "pillwtubes.mx"]
 
 
 def _text(name):
@@ -79,7 +79,11 @@ def test_body_line_wins_over_tag_attribute():
      "Invalid lower boundary condition"),
     ("<S>\n polarization = TE\n <Dielectric>\n </Dielectric>\n</S>", "Dielectric"),
     ("<S>\n polarization = TE\n <Mu>\n </Mu>\n</S>", "<Mu>"),
-    ("<S>\n polarization = TE\n <PEC>\n <Torus>\n name = t\n </Torus>\n </PEC>\n</S>", "Torus"),
+    ("<S>\n polarization = TE\n <PEC>\n <Torus>\n name = t\n </Torus>\n </PEC>\n</S>", "major radius"),
+    ("<S>\n polarization = TE\n <PEC>\n <ShapeSubtract>\n <Sphere>\n name = a\n </Sphere>\n </ShapeSubtract>\n </PEC>\n</S>",
+     "exactly 2"),
+    ("<S>\n polarization = TE\n <PEC>\n <ShapeMirror>\n normal = [0,0,1]\n point in plane = [0,0,0]\n </ShapeMirror>\n </PEC>\n</S>",
+     "one shape block"),
     ("<S>\n polarization = TE\n <Eigensolver>\n <LinearSolver>\n <Preconditioner>\n type = foo\n </Preconditioner>\n"
      " </LinearSolver>\n </Eigensolver>\n</S>", "Preconditioner type"),
     ("<S>\n polarization = TE\n <Grid>\n</S>", "parse error"),
@@ -91,9 +95,11 @@ def test_errors_are_reported(text, needle):
     assert needle in str(e.value)
 
 
-@pytest.mark.parametrize("name", ["pillbox.mx", "tilted_cavity.mx"])
+@pytest.mark.parametrize("name", ["pillbox.mx", "tilted_cavity.mx", "crabcell.mx", "pillwtubes.mx"])
 def test_pec_level_set_bit_identical(name):
-    """Shape factory + transforms in document order: the level set equals the restatement's bit for bit."""
+    """Shape factory + transforms in document order: the level set equals the restatement's bit for bit.
+    crabcell / pillwtubes cover every remaining shape tag of src/MxProblem.cpp:8-17 (Ellipsoid, Torus, Cone,
+    ShapeSubtract / Union / Mirror / Repeat)."""
     deck = mxdeck.Deck(_text(name))
     prob = mx.Problem(text=_text(name))
     rng = np.random.default_rng(7)
