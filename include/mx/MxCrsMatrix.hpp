@@ -39,6 +39,13 @@ class MxCrsMatrix {
   MxCrsMatrix(RCP<MxMap> rowMap, RCP<MxMap> colMap, mx::Csr<Scalar> const& csr)
       : mFilled(false), mRowMap(rowMap), mColMap(colMap), mDev(nullptr) { adopt(csr); }
 
+  // Row-partitioned operator of a decomposed grid: the owned rows with GLOBAL column ids.  Columns this rank
+  // does not own become ghosts and the import plan is agreed with the other ranks here, which is what Epetra's
+  // FillComplete does (src/MxCrsMatrix.cpp:325-342).  COLLECTIVE: every rank constructs its part in the same order.
+  MxCrsMatrix(RCP<MxMap> rowMap, RCP<MxMap> domainMap, mx::UVec<int64_t> const& rowptr,
+              mx::UVec<int64_t> const& colGids, mx::UVec<Scalar> const& vals)
+      : mFilled(false), mRowMap(rowMap), mColMap(domainMap), mDev(nullptr) { adoptDistributed(rowptr, colGids, vals); }
+
   ~MxCrsMatrix() { if (mDev) mxg_csr_destroy(mDev); }
 
   // indices are always global here
@@ -179,17 +186,126 @@ class MxCrsMatrix {
   }
   void ensureDevice() const {
     if (mDev) return;
-    MX_ABI(mxg_csr_create(mRowMap->getComm()->getCtx(), mHost.nrows, mHost.ncols, 0, mHost.rowptr.data(),
+    mxg_halo_plan plan;
+    plan.nneigh = (int)mNeigh.size();
+    plan.neigh = mNeigh.data();
+    plan.send_off = mSendOff.data();
+    plan.send_idx = mSendIdx.empty() ? &mNoIdx : mSendIdx.data();
+    plan.recv_off = mRecvOff.data();
+    const bool halo = mDistributed && !mNeigh.empty();
+    MX_ABI(mxg_csr_create(mRowMap->getComm()->getCtx(), mHost.nrows, mHost.ncols - mNumGhost, mNumGhost, mHost.rowptr.data(),
                           mHost.col.data(), reinterpret_cast<const double*>(mHost.val.data()),
-                          ScalarTraits<Scalar>::isComplex, NULL, &mDev), "MxCrsMatrix::fillComplete");
+                          ScalarTraits<Scalar>::isComplex, halo ? &plan : NULL, &mDev), "MxCrsMatrix::fillComplete");
     // structured operators stream 3 bytes per entry instead of 12 (mxg_csr_compress; bit-identical results);
-    // MXG_COMPRESS=0 keeps the plain CSR kernels
+    // MXG_COMPRESS=0 keeps the plain CSR kernels.  Operators with ghost columns keep the CSR kernel, whose
+    // interior blocks overlap the halo exchange.
     static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
-    if (compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 4096)
+    if (compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 4096 && mNumGhost == 0)
       MX_ABI(mxg_csr_compress_from(mDev, mHost.rowptr.data(), mHost.col.data(),
                                    reinterpret_cast<const double*>(mHost.val.data()), NULL, NULL, NULL),
              "MxCrsMatrix::fillComplete (compress)");
   }
+  // ghosts = the global column ids this rank does not own, grouped by owner (ascending rank, then ascending id);
+  // local column numbering [owned | ghosts].  One all-gather of the need lists gives every rank its send side.
+  void adoptDistributed(mx::UVec<int64_t> const& rowptr, mx::UVec<int64_t> const& colGids, mx::UVec<Scalar> const& vals) {
+    RCP<MxComm> comm = mRowMap->getComm();
+    const int me = comm->myPID(), np = comm->numProc();
+    const int64_t nowned = (int64_t)mColMap->getNodeNumIndices(), nnz = (int64_t)colGids.size();
+    mx::UVec<int64_t> lc(nnz);
+    std::vector<std::pair<int64_t, int64_t> > need;   // (owner, gid)
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < nnz; ++q) {
+      const MxIndex l = mColMap->getLocalIndex((MxIndex)colGids[q]);
+      lc[q] = l == MxIndex(-1) ? -1 : (int64_t)l;
+    }
+    for (int64_t q = 0; q < nnz; ++q) if (lc[q] < 0) need.push_back(std::make_pair((int64_t)0, colGids[q]));
+    if (!need.empty() && (np == 1 || !mColMap->hasOwnerFunction())) {
+      std::cout << "MxCrsMatrix: column " << need[0].second << " is not in the domain map of this rank and the map has no owner directory\n";
+      throw 1;
+    }
+    for (auto& e : need) e.first = mColMap->ownerOf((MxIndex)e.second);
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    mNumGhost = (int64_t)need.size();
+    for (int64_t q = 0; q < nnz; ++q)
+      if (lc[q] < 0) {
+        const std::pair<int64_t, int64_t> key((int64_t)mColMap->ownerOf((MxIndex)colGids[q]), colGids[q]);
+        lc[q] = nowned + (std::lower_bound(need.begin(), need.end(), key) - need.begin());
+      }
+    mHost.nrows = (int64_t)mRowMap->getNodeNumIndices();
+    mHost.ncols = nowned + mNumGhost;
+    if (mHost.ncols >= ((int64_t)1 << 31)) { std::cout << "MxCrsMatrix: more than 2^31 local columns\n"; throw 1; }
+    mHost.rowptr.assign(rowptr.begin(), rowptr.end());
+    mHost.col.resize(nnz);
+    for (int64_t q = 0; q < nnz; ++q) mHost.col[q] = (int32_t)lc[q];
+    mHost.val.assign(vals.begin(), vals.end());
+    mDistributed = true;
+    // plan agreement
+    mx::UVec<int64_t> flat(2 * need.size());
+    for (size_t i = 0; i < need.size(); ++i) { flat[2 * i] = need[i].first; flat[2 * i + 1] = need[i].second; }
+    std::vector<int64_t> counts(np, 0);
+    MX_ABI(mxg_comm_allgather_i64(comm->getCtx(), (int64_t)(flat.size() * sizeof(int64_t)), counts.data()), "MxCrsMatrix (plan sizes)");
+    int64_t total = 0;
+    std::vector<int64_t> off(np + 1, 0);
+    for (int r = 0; r < np; ++r) { off[r + 1] = off[r] + counts[r] / (int64_t)sizeof(int64_t); total += counts[r]; }
+    mx::UVec<int64_t> all((size_t)(total / (int64_t)sizeof(int64_t)) + 1);
+    MX_ABI(mxg_comm_allgatherv(comm->getCtx(), flat.data(), (int64_t)(flat.size() * sizeof(int64_t)), counts.data(), all.data()),
+           "MxCrsMatrix (plan exchange)");
+    std::vector<std::vector<int64_t> > wanted(np);    // owned local indices rank r asks of me, in r's ghost order
+    for (int r = 0; r < np; ++r) {
+      if (r == me) continue;
+      for (int64_t i = off[r]; i < off[r + 1]; i += 2) {
+        if (all[i] != me) continue;
+        const MxIndex l = mColMap->getLocalIndex((MxIndex)all[i + 1]);
+        if (l == MxIndex(-1)) { std::cout << "MxCrsMatrix: rank " << r << " asks rank " << me << " for entry " << all[i + 1] << ", which it does not own\n"; throw 1; }
+        wanted[r].push_back((int64_t)l);
+      }
+    }
+    mNeigh.clear(); mSendOff.assign(1, 0); mRecvOff.assign(1, 0); mSendIdx.clear();
+    size_t g = 0;
+    for (int r = 0; r < np; ++r) {
+      int64_t nrecv = 0;
+      while (g < need.size() && need[g].first == r) { ++g; ++nrecv; }
+      if (nrecv == 0 && wanted[r].empty()) continue;
+      mNeigh.push_back(r);
+      mSendIdx.insert(mSendIdx.end(), wanted[r].begin(), wanted[r].end());
+      mSendOff.push_back((int64_t)mSendIdx.size());
+      mRecvOff.push_back(mRecvOff.back() + nrecv);
+    }
+    mFilled = true;
+  }
+
+ public:
+  bool isDistributed() const { return mDistributed; }
+  int64_t numGhosts() const { return mNumGhost; }
+  // square part on the owned columns (the block a rank-local preconditioner works on)
+  mx::Csr<Scalar> ownedBlock() const {
+    mx::Csr<Scalar> b;
+    const int64_t nowned = mHost.ncols - mNumGhost;
+    b.nrows = mHost.nrows; b.ncols = nowned;
+    b.rowptr.resize(b.nrows + 1);
+    b.rowptr[0] = 0;
+    for (int64_t i = 0; i < mHost.nrows; ++i) {
+      int64_t c = 0;
+      for (int64_t q = mHost.rowptr[i]; q < mHost.rowptr[i + 1]; ++q) c += mHost.col[q] < nowned;
+      b.rowptr[i + 1] = b.rowptr[i] + c;
+    }
+    b.col.resize(b.rowptr[b.nrows]); b.val.resize(b.rowptr[b.nrows]);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < mHost.nrows; ++i) {
+      int64_t o = b.rowptr[i];
+      for (int64_t q = mHost.rowptr[i]; q < mHost.rowptr[i + 1]; ++q)
+        if (mHost.col[q] < nowned) { b.col[o] = mHost.col[q]; b.val[o] = mHost.val[q]; ++o; }
+    }
+    return b;
+  }
+
+ private:
+  bool mDistributed = false;
+  int64_t mNumGhost = 0;
+  int64_t mNoIdx = 0;
+  std::vector<int> mNeigh;
+  std::vector<int64_t> mSendOff, mSendIdx, mRecvOff;
   bool mFilled;
   RCP<MxMap> mRowMap, mColMap;
   std::vector<std::vector<std::pair<MxIndex, Scalar> > > mRows;

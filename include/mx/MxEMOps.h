@@ -80,11 +80,30 @@ class MxEMOps {
     else if (name == "gradPsi") { cols = p; }
     else if (name == "dmL" || name == "invEps") { rows = e; cols = e; }
     else if (name == "dmVInv" || name == "invEpsVolAve" || name == "scaLapl") { rows = p; cols = p; }
-    mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, m));
+    if (!mSim->isDistributed()) { mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, m)); return; }
+    mOps[name] = distributed(rows, cols, fieldOf(rows, b, e), fieldOf(cols, b, e), m);
+  }
+  // the owned rows of a window-level operator (box + halo numbering) as a row-partitioned matrix; COLLECTIVE
+  RCP<MxCrsMatrix<Scalar> > distributed(RCP<MxMap> rows, RCP<MxMap> cols, const mx::YeeField& rowF, const mx::YeeField& colF,
+                                        mx::Csr<Scalar> const& m) const {
+    const mx::YeeAssembler<Scalar>& a = mSim->assemblerFor((Scalar*)0);
+    mx::Csr<Scalar> o = a.ownedRows(m, rowF);
+    mx::UVec<int64_t> colg(o.col.size());
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < (int64_t)o.col.size(); ++q) colg[q] = colF.gids[o.col[q]];
+    return rcp(new MxCrsMatrix<Scalar>(rows, cols, o.rowptr, colg, o.val));
+  }
+  const mx::YeeField& fieldOf(RCP<MxMap> map, RCP<MxMap> b, RCP<MxMap> e) const {
+    const mx::YeeAssembler<Scalar>& a = mSim->assemblerFor((Scalar*)0);
+    return map.get() == b.get() ? a.bfield() : (map.get() == e.get() ? a.efield() : a.psifield());
   }
   void saveOps() const { for (auto& e : mOps) e.second->save("Mx" + e.first); }
  private:
   void insert(const char* name, RCP<MxMap> rows, RCP<MxMap> cols, mx::Csr<Scalar> const& m) {
+    if (mSim->isDistributed()) {
+      std::cout << "MxEMOps: on a decomposed grid the operator chain is formed on the box + halo window (prebuilt operators)\n";
+      throw 1;
+    }
     mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, m));
   }
   int pid;

@@ -8,6 +8,7 @@
 #include "MxMap.hpp"
 #include "MxMultiVector.hpp"
 #include "mx_yee.hpp"   // maxwell_amd/csrc/host (on the include path of the host library)
+#include "mxh.h"
 
 template <size_t DIM> class MxEMSim;
 
@@ -76,6 +77,9 @@ class MxEMSim {
     mPList.set("has curl null", true);
   }
   bool isComplex() const { return mComplex; }
+  // true when this rank holds one MxGridDomain box of a decomposed grid
+  bool isDistributed() const { return mWindowed; }
+  const mx::YeeConfig& getConfig() const { return mCfg; }
   // operators already assembled for this configuration (the mxh_sim of the C ABI computes the whole chain for
   // export); MxMagWaveOp::initMatrices adopts them instead of repeating the products.  Real problems only.
   typedef std::map<std::string, mx::Csr<double> > OpCache;
@@ -107,14 +111,51 @@ class MxEMSim {
  private:
   template <typename A>
   void addFields(const A& a, RCP<MxComm> comm) {
+    mWindowed = a.isWindowed();
+    if (mWindowed) {
+      // one rank per MxGridDomain box (src/MxGrid.cpp:171-193): the box of the configuration must be this rank's
+      int lo[3], hi[3];
+      if (mxh_partition(mCfg.n, comm->numProc(), comm->myPID(), mProcGrid, lo, hi) != 0) throw 1;
+      for (int i = 0; i < 3; ++i) {
+        const int chi = mCfg.boxHi[i] < 0 ? mCfg.n[i] + 1 : mCfg.boxHi[i];
+        if (lo[i] != mCfg.boxLo[i] || hi[i] != chi) {
+          std::cout << "MxEMSim: the cell box of the configuration is not the box of rank " << comm->myPID() << " of "
+                    << comm->numProc() << " (MxGrid::getGridDomain)\n";
+          throw 1;
+        }
+      }
+    } else if (comm->numProc() > 1) {
+      std::cout << "MxEMSim: " << comm->numProc() << " ranks need a configuration restricted to this rank's cell box\n";
+      throw 1;
+    }
     addField("bfield", a.bfield(), a.usedMask(), comm);
     addField("efield", a.efield(), std::vector<double>(), comm);
     addField("psifield", a.psifield(), std::vector<double>(), comm);
     if (hasDielectric()) mFields["dfield"] = mFields["efield"];   // dfield->setMap(efield), src/MxEMSim.cpp:196-197
   }
   void addField(const char* name, const mx::YeeField& f, std::vector<double> mask, RCP<MxComm> comm) {
-    std::vector<MxIndex> g(f.gids.begin(), f.gids.end());
-    RCP<MxMap> map = rcp(new MxMap(g, comm));
+    std::vector<MxIndex> g;
+    RCP<MxMap> map;
+    if (!mWindowed) {
+      g.assign(f.gids.begin(), f.gids.end());
+      map = rcp(new MxMap(g, comm));
+    } else {
+      // owned entries only (ascending global id); ghosts are a matter of each operator (MxCrsMatrix)
+      std::vector<double> m2;
+      for (size_t r = 0; r < f.gids.size(); ++r)
+        if (f.owned[r]) { g.push_back((MxIndex)f.gids[r]); if (!mask.empty()) m2.push_back(mask[r]); }
+      mask.swap(m2);
+      double total = (double)g.size();
+      MX_ABI(mxg_comm_allreduce_host(comm->getCtx(), &total, 1), "MxEMSim (global map size)");
+      map = rcp(new MxMap((size_t)(total + 0.5), g, comm));
+      const int ncomp = f.ncomp;
+      const int n[3] = {mCfg.n[0], mCfg.n[1], mCfg.n[2]}, pg[3] = {mProcGrid[0], mProcGrid[1], mProcGrid[2]};
+      map->setOwnerFunction([ncomp, n, pg](MxIndex gid) {
+        const int64_t cell = (int64_t)gid / ncomp, d1 = n[1] + 1, d2 = n[2] + 1;
+        const int c[3] = {(int)(cell / (d2 * d1)), (int)((cell / d2) % d1), (int)(cell % d2)};
+        return mxh_owner_of_cell(n, pg, c);
+      });
+    }
     const std::string nm(name);
     const char* cls = nm == "bfield" ? "YeeFitBField" : (nm == "efield" ? "YeeFitEField" : "YeeFitPsiField");
     mFields[name] = std::make_shared<MxGridField<DIM> >(name, map, mask, f.ncomp, cls, mCfg.n);
@@ -123,6 +164,8 @@ class MxEMSim {
   MxGrid<DIM> mGrid;
   Teuchos::ParameterList mPList;
   bool mComplex = false;
+  bool mWindowed = false;
+  int mProcGrid[3] = {1, 1, 1};
   const OpCache* mPrebuilt = nullptr;
   std::shared_ptr<mx::YeeAssembler<double> > mAsm;
   mutable std::shared_ptr<mx::YeeAssembler<MxComplex> > mAsmC;

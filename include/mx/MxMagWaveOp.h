@@ -101,9 +101,15 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
 
   // shiftedVecLapl = vecLapl - shift * mRhs  (:248-255)
   void setShift(Scalar newShift) {
-    mShiftedVecLapl = rcp(new MxCrsMatrix<Scalar>(mBMap));
-    MxCrsMatrix<Scalar>::matrixMatrixAdd(*mVecLapl, false, ScalarTraits<Scalar>::one(), *mRhs, false, -newShift,
-                                         *mShiftedVecLapl, true);
+    if (mSim->isDistributed()) {
+      // decomposed grid: the sum is formed on the box + halo window, its owned rows become the row-partitioned
+      // matrix (ghost import agreed with the neighbours - collective)
+      mShiftedVecLapl = shiftedDistributed(newShift, (Scalar*)0);
+    } else {
+      mShiftedVecLapl = rcp(new MxCrsMatrix<Scalar>(mBMap));
+      MxCrsMatrix<Scalar>::matrixMatrixAdd(*mVecLapl, false, ScalarTraits<Scalar>::one(), *mRhs, false, -newShift,
+                                           *mShiftedVecLapl, true);
+    }
     setLinearSolvers();
   }
 
@@ -165,8 +171,21 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   static MxComplex toScalarImpl(std::complex<double> z, MxComplex*) { return z; }
   static Scalar toScalar(std::complex<double> z) { return toScalarImpl(z, (Scalar*)0); }
 
+  RCP<MxCrsMatrix<Scalar> > shiftedDistributed(Scalar, MxComplex*) { return RCP<MxCrsMatrix<Scalar> >(); }
+  RCP<MxCrsMatrix<Scalar> > shiftedDistributed(Scalar newShift, double*) {
+    const typename MxEMSim<DIM>::OpCache* pre = mSim->prebuiltOps((double*)0);
+    const mx::YeeAssembler<double>& a = mSim->getAssembler();
+    mx::Csr<double> sh = mx::add(pre->at("vecLapl"), 1.0, pre->at("mRhs"), -newShift);
+    return mEMOps->distributed(mBMap, mBMap, a.bfield(), a.bfield(), sh);
+  }
+
   void initMatrices() {   // :138-245
     if (adoptPrebuilt((Scalar*)0)) return;
+    if (mSim->isDistributed()) {
+      std::cout << "MxMagWaveOp: a decomposed grid needs the real operator chain formed on the box + halo window "
+                   "(MxEMSim::setPrebuiltOps); complex problems are single-rank for now\n";
+      throw 1;
+    }
     mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim));
     std::vector<std::string> names;
     names.push_back("curlB");
@@ -269,8 +288,8 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mOpts.max_iters = mPList.get("linear solver : max iters", 0);
     mOpts.cheb_degree = 0; mOpts.lmin = 0; mOpts.lmax = 0; mOpts.mg = nullptr;
     if (mUseMg) {
-      if (mBMap->getComm()->numProc() > 1 || ScalarTraits<Scalar>::isComplex) {
-        if (pid == 0) std::cout << "MxMagWaveOp: multigrid is single-rank and real for now -> Jacobi.\n";
+      if (ScalarTraits<Scalar>::isComplex) {
+        if (pid == 0) std::cout << "MxMagWaveOp: multigrid is real for now -> Jacobi.\n";
         mOpts.precond = 1; mUseMg = false;
       } else {
         buildMultigrid((Scalar*)0);
@@ -285,6 +304,16 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     const mx::YeeAssembler<double>& a = mSim->getAssembler();
     mxg_ctx* ctx = mBMap->getComm()->getCtx();
     if (mVecMg) mxh_mg_destroy(mVecMg);
+    if (mSim->isDistributed()) {
+      // one hierarchy per rank on the block of its own columns (no communication inside the V-cycle): the
+      // preconditioner of the global solve is block-diagonal over the MxGridDomain boxes, symmetric like its blocks
+      mVecMg = mxh_mg_build_gids(ctx, mShiftedVecLapl->ownedBlock(), a.ownedGids(a.bfield()), 3, a.config().n, 2000, levels,
+                                 sweeps, 30, 0.85, 1.9);
+      if (mHasCurlNull && !mScaMg)
+        mScaMg = mxh_mg_build_gids(ctx, mScaLapl->ownedBlock(), a.ownedGids(a.psifield()), 1, a.config().n, 2000, levels,
+                                   sweeps, 30, 0.85, 1.9);
+      return;
+    }
     mVecMg = mxh_mg_build(ctx, mShiftedVecLapl->getHostCsr(), a.bfield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);
     if (mHasCurlNull && !mScaMg)
       mScaMg = mxh_mg_build(ctx, mScaLapl->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);

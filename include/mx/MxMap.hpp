@@ -3,6 +3,7 @@
 #define MX_MAP
 
 #include <algorithm>
+#include <functional>
 #include <unordered_map>
 
 #include "MxComm.hpp"
@@ -38,6 +39,11 @@ class MxMap {
   MxIndex const* getNodeIndexList() const { return gids_.data(); }
   const std::vector<MxIndex>& getNodeIndices() const { return gids_; }
   RCP<MxComm> getComm() const { return comm_; }
+  // rank owning a global index that is not local (the directory Epetra builds with MPI; here the grid
+  // partition answers it, src/MxGrid.cpp:171-193); set by MxEMSim for the maps of a decomposed grid
+  void setOwnerFunction(std::function<int(MxIndex)> f) { owner_ = f; }
+  bool hasOwnerFunction() const { return (bool)owner_; }
+  int ownerOf(MxIndex gid) const { return owner_(gid); }
 
  private:
   void buildLookup() {
@@ -49,6 +55,7 @@ class MxMap {
   size_t numGlobal_;
   bool sorted_ = true;
   std::unordered_map<MxIndex, MxIndex> lookup_;
+  std::function<int(MxIndex)> owner_;
 };
 
 #endif

@@ -54,6 +54,20 @@ int mxg_timer_stop(mxg_ctx* ctx, float* elapsed_ms);
 /* Comm::Barrier (src/MxMagWaveOp.cpp:71,288): stream sync + zero-byte all-reduce */
 int mxg_barrier(mxg_ctx* ctx);
 
+/* In-process world: the ranks are threads of one process sharing `device` (several MxGridDomain boxes on one
+ * GPU, src/MxGrid.cpp:171-193).  Same collectives as the RCCL world, staged through the host; every rank
+ * thread must issue them in the same order.  Create one world, then one ctx per rank thread. */
+typedef struct mxg_local_world mxg_local_world;
+int mxg_local_world_create(int nranks, mxg_local_world** out);
+int mxg_local_world_destroy(mxg_local_world* w);
+int mxg_ctx_create_local(int device, int rank, int nranks, mxg_local_world* w, mxg_ctx** out);
+/* Setup-time collectives on host data (the plan agreement Epetra's FillComplete does with MPI,
+ * src/MxCrsMatrix.cpp:325-342): one int64 per rank; variable-length byte strings concatenated in rank
+ * order (counts[r] = bytes of rank r); sum of doubles.  No-ops on a single rank. */
+int mxg_comm_allgather_i64(mxg_ctx* ctx, int64_t v, int64_t* out);
+int mxg_comm_allgatherv(mxg_ctx* ctx, const void* send, int64_t nbytes, const int64_t* counts, void* recv);
+int mxg_comm_allreduce_host(mxg_ctx* ctx, double* v, int n);
+
 /* ------------------------------------------------------------------------------------------
  * halo plan  (replaces the Epetra_Import built by FillComplete, src/MxCrsMatrix.cpp:325-342)
  *

@@ -71,6 +71,17 @@ int mxh_sim_dist_op(mxh_sim* s, const char* name, double shift, int64_t* nrows, 
                     const int64_t** row_gids, int64_t* n_owned_cols, const int64_t** col_field_owned_gids,
                     int* col_ncomp);
 
+/* The same through the C++ classes (MxEMSim maps of the owned entries, MxCrsMatrix with the ghost import agreed
+ * between the ranks with mxg_comm_* collectives - what Epetra's FillComplete does, src/MxCrsMatrix.cpp:325-342).
+ * `sim` is this rank's box simulation (mxh_sim_create_box with the box of mxh_partition); every call is COLLECTIVE
+ * over the ranks of `ctx`.  mxh_dist_ops_matrix returns the device matrix (owned by the handle) of a named operator
+ * or of vecLapl - shift*mRhs ("shifted"), its owned row ids and the owned ids of its column field (ascending). */
+typedef struct mxh_dist_ops mxh_dist_ops;
+int mxh_dist_ops_create(mxg_ctx* ctx, mxh_sim* sim, mxh_dist_ops** out);
+int mxh_dist_ops_matrix(mxh_dist_ops* d, const char* name, double shift, mxg_csr** A, int64_t* nrows,
+                        const int64_t** row_gids, int64_t* ncols_owned, const int64_t** col_gids, int64_t* nghost);
+int mxh_dist_ops_destroy(mxh_dist_ops* d);
+
 /* Borrowed views (valid until mxh_sim_destroy) of a named operator in local CSR form:
  * curlE curlB divB gradPsi dmA dmL dmVInv curlCurl gradDiv vecLapl scaLapl mRhs
  * (MxEMOps::getOp, src/MxEMOps.cpp:171-183; MxMagWaveOp::initMatrices, src/MxMagWaveOp.cpp:138-245) */

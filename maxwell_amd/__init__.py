@@ -10,4 +10,4 @@ There is no CPU fallback: importing works without a GPU (so the build and the sy
 run anywhere), but every compute call goes to the HIP library and raises if it is missing.
 """
 from ._lib import load_mxg, load_mxhost, MxError  # noqa: F401
-from .api import Ctx, CsrMatrix, MultiVec, Multigrid, Problem, Sim, Solver, SolverParams  # noqa: F401
+from .api import Ctx, CsrMatrix, LocalWorld, MultiVec, Multigrid, Problem, Sim, Solver, SolverParams  # noqa: F401

@@ -50,6 +50,12 @@ MXG_SIGNATURES = {
     "mxg_timer_start": (C.c_int, [vp]),
     "mxg_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "mxg_barrier": (C.c_int, [vp]),
+    "mxg_local_world_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "mxg_local_world_destroy": (C.c_int, [vp]),
+    "mxg_ctx_create_local": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "mxg_comm_allgather_i64": (C.c_int, [vp, C.c_int64, c_i64p]),
+    "mxg_comm_allgatherv": (C.c_int, [vp, vp, C.c_int64, c_i64p, vp]),
+    "mxg_comm_allreduce_host": (C.c_int, [vp, c_dp, C.c_int]),
     "mxg_csr_create": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, C.c_int,
                                  C.POINTER(HaloPlan), C.POINTER(vp)]),
     "mxg_csr_destroy": (C.c_int, [vp]),
@@ -103,6 +109,10 @@ MXH_SIGNATURES = {
     "mxh_sim_create_ex": (C.c_int, [C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_char_p),
                                     C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_double, C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp)]),
+    "mxh_dist_ops_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "mxh_dist_ops_matrix": (C.c_int, [vp, C.c_char_p, C.c_double, C.POINTER(vp), c_i64p, C.POINTER(c_i64p), c_i64p,
+                                      C.POINTER(c_i64p), c_i64p]),
+    "mxh_dist_ops_destroy": (C.c_int, [vp]),
     "mxh_sim_dist_op": (C.c_int, [vp, C.c_char_p, C.c_double, c_i64p, c_i64p, C.POINTER(c_i64p),
                                   C.POINTER(c_i64p), C.POINTER(c_dp), C.POINTER(c_i64p), c_i64p,
                                   C.POINTER(c_i64p), c_ip]),

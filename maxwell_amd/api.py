@@ -23,13 +23,62 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class LocalWorld:
+    """In-process world (mxg_local_world): `nranks` rank threads of this process share one device, with the
+    same collectives as the RCCL world.  `run(fn)` starts one thread per rank with its own Ctx and returns the
+    list of results; an exception in any rank is re-raised."""
+
+    def __init__(self, nranks, device=0):
+        self.lib = _lib.load_mxg()
+        self.nranks, self.device = nranks, device
+        h = C.c_void_p()
+        _chk(self.lib.mxg_local_world_create(nranks, C.byref(h)), self.lib)
+        self.h = h
+
+    def run(self, fn):
+        import threading
+        out, err = [None] * self.nranks, [None] * self.nranks
+
+        def body(r):
+            ctx = None
+            try:
+                ctx = Ctx(self.device, r, self.nranks, world=self)
+                out[r] = fn(ctx)
+            except BaseException as e:          # noqa: BLE001 - reported to the caller below
+                err[r] = e
+            finally:
+                if ctx is not None:
+                    ctx.close()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.nranks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.mxg_local_world_destroy(self.h)
+            self.h = None
+
+
 class Ctx:
     """One GPU / rank (replaces MxComm, src/MxComm.hpp:14-37)."""
 
-    def __init__(self, device=0, rank=0, nranks=1, unique_id=None):
+    def __init__(self, device=0, rank=0, nranks=1, unique_id=None, world=None):
         self.lib = _lib.load_mxg()
         h = C.c_void_p()
         uid = None
+        self.world = world
+        if world is not None:            # in-process world: this rank is a thread sharing the device
+            _chk(self.lib.mxg_ctx_create_local(device, rank, nranks, world.h, C.byref(h)), self.lib)
+            self.h = h
+            self.rank, self.nranks = rank, nranks
+            return
         if unique_id is not None:
             self._uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
             uid = C.cast(self._uid, C.c_void_p)

@@ -1322,21 +1322,13 @@ static int halo_exchange(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, MvDesc* xext) 
     }
   }
   MXG_HIP(hipGetLastError());
-  MXG_CHECK(c->comm != nullptr, "halo exchange needs an RCCL communicator (nranks > 1)");
-  MXG_NCCL(ncclGroupStart());
-  for (int j = 0; j < k; ++j) {
-    for (int p = 0; p < a->nneigh; ++p) {
-      const int64_t ns = (a->send_off[p + 1] - a->send_off[p]) * w;
-      const int64_t nr = (a->recv_off[p + 1] - a->recv_off[p]) * w;
-      if (ns > 0)
-        MXG_NCCL(ncclSend(a->d_sendbuf + (a->nsend * j + a->send_off[p]) * w, ns, ncclDouble,
-                          a->neigh[p], c->comm, c->stream));
-      if (nr > 0)
-        MXG_NCCL(ncclRecv(a->d_xext + ldx * j + (a->ncols_owned + a->recv_off[p]) * w, nr,
-                          ncclDouble, a->neigh[p], c->comm, c->stream));
-    }
-  }
-  MXG_NCCL(ncclGroupEnd());
+  MXG_CHECK(mxg_comm_on(c), "halo exchange needs a communicator (nranks > 1)");
+  std::vector<MxgXfer> xf;
+  for (int j = 0; j < k; ++j)
+    for (int p = 0; p < a->nneigh; ++p)
+      xf.push_back({a->neigh[p], a->d_sendbuf + (a->nsend * j + a->send_off[p]) * w, (a->send_off[p + 1] - a->send_off[p]) * w,
+                    a->d_xext + ldx * j + (a->ncols_owned + a->recv_off[p]) * w, (a->recv_off[p + 1] - a->recv_off[p]) * w});
+  MXG_TRY(mxg_comm_exchange(c, xf.data(), (int)xf.size(), c->stream));
   xext->base = a->d_xext; xext->ld = ldx; xext->n = next; xext->k = k; xext->cplx = a->is_complex;
   xext->col0 = 0; xext->cols = nullptr;
   return 0;
@@ -1367,20 +1359,15 @@ static int halo_start(mxg_ctx* c, mxg_csr* a, const mxg_mv* x) {
                        (const long long*)a->d_send_idx, (long long)a->nsend, 1, a->d_sendbuf + a->nsend * j);
   }
   MXG_HIP(hipGetLastError());
-  MXG_CHECK(c->comm != nullptr, "halo exchange needs an RCCL communicator (nranks > 1)");
+  MXG_CHECK(mxg_comm_on(c), "halo exchange needs a communicator (nranks > 1)");
   MXG_HIP(hipEventRecord(c->ev_pack, c->stream));
   MXG_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
-  MXG_NCCL(ncclGroupStart());
+  std::vector<MxgXfer> xf;
   for (int j = 0; j < k; ++j)
-    for (int p = 0; p < a->nneigh; ++p) {
-      const int64_t ns = a->send_off[p + 1] - a->send_off[p];
-      const int64_t nr = a->recv_off[p + 1] - a->recv_off[p];
-      if (ns > 0)
-        MXG_NCCL(ncclSend(a->d_sendbuf + a->nsend * j + a->send_off[p], ns, ncclDouble, a->neigh[p], c->comm, c->comm_stream));
-      if (nr > 0)
-        MXG_NCCL(ncclRecv(a->d_ghost + ldg * j + a->recv_off[p], nr, ncclDouble, a->neigh[p], c->comm, c->comm_stream));
-    }
-  MXG_NCCL(ncclGroupEnd());
+    for (int p = 0; p < a->nneigh; ++p)
+      xf.push_back({a->neigh[p], a->d_sendbuf + a->nsend * j + a->send_off[p], a->send_off[p + 1] - a->send_off[p],
+                    a->d_ghost + ldg * j + a->recv_off[p], a->recv_off[p + 1] - a->recv_off[p]});
+  MXG_TRY(mxg_comm_exchange(c, xf.data(), (int)xf.size(), c->comm_stream));
   MXG_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
   return 0;
 }

@@ -116,9 +116,9 @@ extern "C" int mxg_timer_stop(mxg_ctx* c, float* ms) {
 }
 
 extern "C" int mxg_barrier(mxg_ctx* c) {
-  if (c->comm) {
+  if (mxg_comm_on(c)) {
     MXG_HIP(hipMemsetAsync(c->d_result, 0, sizeof(double), c->stream));
-    MXG_NCCL(ncclAllReduce(c->d_result, c->d_result, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    MXG_TRY(mxg_comm_allreduce(c, c->d_result, 1, c->stream));
   }
   MXG_HIP(hipStreamSynchronize(c->stream));
   return 0;
@@ -160,11 +160,8 @@ int mxg_ctx_reserve_scratch(mxg_ctx* c, size_t doubles) {
 }
 
 int mxg_ctx_finish_reduce(mxg_ctx* c, size_t width, double* host_out) {
-  if (c->comm) {
-    // C2: the MPI_Allreduce inside Epetra_MultiVector::Dot / Norm2 / Multiply('T', ...)
-    MXG_NCCL(ncclAllReduce(c->d_result, c->d_result, width, ncclDouble, ncclSum, c->comm,
-                           c->stream));
-  }
+  // C2: the MPI_Allreduce inside Epetra_MultiVector::Dot / Norm2 / Multiply('T', ...)
+  if (mxg_comm_on(c)) MXG_TRY(mxg_comm_allreduce(c, c->d_result, width, c->stream));
   MXG_HIP(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * width, hipMemcpyDeviceToHost,
                          c->stream));
   MXG_HIP(hipStreamSynchronize(c->stream));

@@ -58,6 +58,7 @@ struct mxg_ctx {
   int nranks = 1;
   hipStream_t stream = nullptr;
   ncclComm_t comm = nullptr;
+  struct mxg_local_world* lw = nullptr;   // in-process world (ranks = threads sharing the device), mxg_comm.hip
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // halo exchange runs on its own stream so that interior rows overlap it (ev_pack / ev_halo order the two)
   hipStream_t comm_stream = nullptr;
@@ -157,6 +158,12 @@ struct mxg_csr {
 };
 
 bool mxg_ctx_alive(const mxg_ctx* c);
+
+// collectives (mxg_comm.hip): RCCL, or the in-process world when the ctx was made by mxg_ctx_create_local
+struct MxgXfer { int peer; const double* send; int64_t ns; double* recv; int64_t nr; };
+bool mxg_comm_on(const mxg_ctx* c);
+int mxg_comm_allreduce(mxg_ctx* c, double* d, size_t count, hipStream_t s);
+int mxg_comm_exchange(mxg_ctx* c, const MxgXfer* x, int n, hipStream_t s);
 
 // reductions / workspace helpers (mxg_ctx.hip)
 int mxg_ctx_reserve_reduce(mxg_ctx* ctx, size_t width);

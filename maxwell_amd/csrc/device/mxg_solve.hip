@@ -312,8 +312,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
   double* scal = c->d_result;
   const double* diag = o->precond == 1 ? A->d_diag : nullptr;
   auto allreduce = [&](double* ptr, int count) -> int {
-    if (c->comm) MXG_NCCL(ncclAllReduce(ptr, ptr, count, ncclDouble, ncclSum, c->comm, c->stream));
-    return 0;
+    return mxg_comm_on(c) ? mxg_comm_allreduce(c, ptr, (size_t)count, c->stream) : 0;
   };
   double res = 0.0;
   MXG_TRY(true_residual(c, A, b, x, r, &res));
@@ -341,7 +340,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
           MXG_TRY(apply_prec(c, A, o, r, z));
           MXG_TRY(mxg_dev_dot(c, r->desc(), z->desc(), scal + nxt));
         }
-        if (c->comm) {   // r.z and r.r sit in different slots: two tiny all-reduces
+        if (mxg_comm_on(c)) {   // r.z and r.r sit in different slots: two tiny all-reduces
           MXG_TRY(allreduce(scal + nxt, 1));
           MXG_TRY(allreduce(scal + S_RR, 1));
         }

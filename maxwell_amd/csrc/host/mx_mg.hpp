@@ -152,4 +152,8 @@ namespace mx { struct YeeField; }
 mxh_mg* mxh_mg_build(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::YeeField& F, const int n[3],
                      int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
                      double coarse_scale);
+// same for any set of lattice unknowns given by their global ids (the owned block of one rank of a decomposed grid)
+mxh_mg* mxh_mg_build_gids(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::UVec<int64_t>& gids, int ncomp, const int n[3],
+                          int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
+                          double coarse_scale);
 #endif

@@ -33,7 +33,13 @@ static mxg_csr* upload(mxg_ctx* ctx, const mx::Csr<double>& m) {
 mxh_mg* mxh_mg_build(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::YeeField& F, const int n[3],
                      int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
                      double coarse_scale) {
-  mx::MgHierarchy h = mx::buildAggregationHierarchy(A0, F.gids, F.ncomp, n, min_coarse, max_levels);
+  return mxh_mg_build_gids(ctx, A0, F.gids, F.ncomp, n, min_coarse, max_levels, sweeps, coarse_sweeps, omega, coarse_scale);
+}
+
+mxh_mg* mxh_mg_build_gids(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::UVec<int64_t>& gids, int ncomp, const int n[3],
+                          int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
+                          double coarse_scale) {
+  mx::MgHierarchy h = mx::buildAggregationHierarchy(A0, gids, ncomp, n, min_coarse, max_levels);
   std::unique_ptr<mxh_mg> g(new mxh_mg());
   g->ctx = ctx;
   for (auto& m : h.A) { g->A.push_back(upload(ctx, m)); g->rows.push_back(m.nrows); g->nnz.push_back(m.nnz()); }

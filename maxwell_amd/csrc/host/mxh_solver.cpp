@@ -140,3 +140,84 @@ extern "C" int mxh_solver_eigvec(mxh_solver* s, int i, double* out) {
     return 1;
   }
 }
+
+// ---------------------------------------------------------------------------------------
+// Row-partitioned operators of a decomposed grid through the C++ classes (MxEMSim maps of the owned entries,
+// MxCrsMatrix with the ghost import agreed between the ranks)
+// ---------------------------------------------------------------------------------------
+struct mxh_dist_ops {
+  RCP<MxComm> comm;
+  RCP<MxEMSim<3> > sim;
+  RCP<MxEMOps<3, double> > ops;
+  mxh_sim* src = nullptr;
+  std::map<std::string, RCP<MxCrsMatrix<double> > > made;
+  std::map<std::string, std::pair<std::vector<int64_t>, std::vector<int64_t> > > gids;
+};
+
+extern "C" int mxh_dist_ops_create(mxg_ctx* ctx, mxh_sim* sim, mxh_dist_ops** out) {
+  try {
+    if (!ctx || !sim || !out) throw std::runtime_error("mxh_dist_ops_create: NULL argument");
+    std::unique_ptr<mxh_dist_ops> d(new mxh_dist_ops());
+    d->comm = rcp(new MxComm(ctx));
+    d->sim = rcp(new MxEMSim<3>(sim->cfg, d->comm, Teuchos::ParameterList(), sim->asmb));
+    d->sim->setPrebuiltOps(&sim->ops);
+    d->ops = rcp(new MxEMOps<3, double>(d->sim, false));
+    d->src = sim;
+    *out = d.release();
+    return 0;
+  } catch (const std::exception& e) {
+    mxh_set_error(e.what());
+    return 1;
+  } catch (int) {
+    mxh_set_error(std::string("mxh_dist_ops_create failed: ") + mxg_last_error());
+    return 1;
+  }
+}
+
+extern "C" int mxh_dist_ops_matrix(mxh_dist_ops* d, const char* name, double shift, mxg_csr** A, int64_t* nrows,
+                                   const int64_t** row_gids, int64_t* ncols_owned, const int64_t** col_gids,
+                                   int64_t* nghost) {
+  try {
+    const std::string nm(name);
+    char key[96];
+    std::snprintf(key, sizeof(key), "%s@%.17g", name, nm == "shifted" ? shift : 0.0);
+    auto it = d->made.find(key);
+    if (it == d->made.end()) {
+      RCP<MxCrsMatrix<double> > m;
+      if (nm == "shifted") {
+        RCP<MxMap> b = d->sim->getField("bfield").getMap();
+        const mx::YeeField& B = d->sim->getAssembler().bfield();
+        m = d->sim->isDistributed() ? d->ops->distributed(b, b, B, B, mxh_sim_shifted_matrix(d->src, shift))
+                                    : rcp(new MxCrsMatrix<double>(b, b, mxh_sim_shifted_matrix(d->src, shift)));
+      } else {
+        auto op = d->src->ops.find(nm);
+        if (op == d->src->ops.end()) throw std::runtime_error("MxEMOps::getOp: operator '" + nm + "' not found.");
+        d->ops->adopt(nm, op->second);
+        m = d->ops->getOp(nm);
+      }
+      it = d->made.emplace(key, m).first;
+      auto& g = d->gids[key];
+      for (MxIndex v : m->getRangeMap()->getNodeIndices()) g.first.push_back((int64_t)v);
+      for (MxIndex v : m->getDomainMap()->getNodeIndices()) g.second.push_back((int64_t)v);
+    }
+    auto& g = d->gids[key];
+    if (A) *A = it->second->getRawMatrix();
+    if (nrows) *nrows = (int64_t)g.first.size();
+    if (row_gids) *row_gids = g.first.data();
+    if (ncols_owned) *ncols_owned = (int64_t)g.second.size();
+    if (col_gids) *col_gids = g.second.data();
+    if (nghost) *nghost = it->second->numGhosts();
+    return 0;
+  } catch (const std::exception& e) {
+    mxh_set_error(e.what());
+    return 1;
+  } catch (int) {
+    mxh_set_error(std::string("mxh_dist_ops_matrix failed: ") + mxg_last_error());
+    return 1;
+  }
+}
+
+extern "C" int mxh_dist_ops_destroy(mxh_dist_ops* d) {
+  delete d;
+  return 0;
+}

@@ -159,6 +159,56 @@ class LocalOperator:
         return A
 
 
+class DistOps:
+    """The C++ route to the same matrices (mxh_dist_ops_*): MxEMSim maps of the owned entries and MxCrsMatrix, which
+    agrees the ghost import with the other ranks through the collectives of the ctx (RCCL, or the in-process
+    world) - no torch.distributed involved.  Every call is collective."""
+
+    def __init__(self, ctx, sim):
+        self.lib, self.ctx, self.sim = _lib.load_mxhost(), ctx, sim
+        h = C.c_void_p()
+        _chk(self.lib.mxh_dist_ops_create(ctx.h, sim.h, C.byref(h)), self.lib, "mxh")
+        self.h = h
+
+    def matrix(self, name, shift=0.0):
+        return DistMatrix(self, name, shift)
+
+    def close(self):
+        if self.h:
+            self.lib.mxh_dist_ops_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DistMatrix:
+    """Owned rows of a named operator on the device (borrowed from its DistOps)."""
+
+    def __init__(self, ops, name, shift=0.0):
+        if not isinstance(ops, DistOps):            # DistMatrix(ctx, sim, name, shift)
+            raise TypeError("DistMatrix needs a DistOps")
+        self.ops, self.ctx, lib = ops, ops.ctx, ops.lib
+        A = C.c_void_p()
+        nr, nc, ng = C.c_int64(), C.c_int64(), C.c_int64()
+        rg, cg = _lib.c_i64p(), _lib.c_i64p()
+        _chk(lib.mxh_dist_ops_matrix(ops.h, name.encode(), float(shift), C.byref(A), C.byref(nr), C.byref(rg),
+                                     C.byref(nc), C.byref(cg), C.byref(ng)), lib, "mxh")
+        self.h = A
+        self.nrows, self.ncols_owned, self.nghost = nr.value, nc.value, ng.value
+        self.row_gids = np.ctypeslib.as_array(rg, (max(nr.value, 1),))[:nr.value].copy()
+        self.col_gids = np.ctypeslib.as_array(cg, (max(nc.value, 1),))[:nc.value].copy()
+
+    def apply(self, x, y):
+        _chk(self.ctx.lib.mxg_csr_apply(self.ctx.h, self.h, x.h, y.h), self.ctx.lib)
+
+    def apply_bytes(self, k=1):
+        return self.ctx.lib.mxg_csr_apply_bytes(self.h, k)
+
+
 def bench_setup(ctx, n_local, shift):
     """Weak-scaling workload of bench.py: the pillbox cavity of example/pillbox.py on a grid refined so
     that every rank owns an n_local^3-cell box (N = 8: 512^3 Yee cells on 2 x 2 x 2 boxes)."""
