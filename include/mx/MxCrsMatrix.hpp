@@ -5,6 +5,7 @@
 #define MX_CRS_MATRIX
 
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 
 #include "MxVector.hpp"
@@ -227,6 +228,8 @@ class MxCrsMatrix {
     std::sort(need.begin(), need.end());
     need.erase(std::unique(need.begin(), need.end()), need.end());
     mNumGhost = (int64_t)need.size();
+    mGhostGids.resize(need.size());
+    for (size_t i = 0; i < need.size(); ++i) mGhostGids[i] = need[i].second;
     for (int64_t q = 0; q < nnz; ++q)
       if (lc[q] < 0) {
         const std::pair<int64_t, int64_t> key((int64_t)mColMap->ownerOf((MxIndex)colGids[q]), colGids[q]);
@@ -278,6 +281,52 @@ class MxCrsMatrix {
  public:
   bool isDistributed() const { return mDistributed; }
   int64_t numGhosts() const { return mNumGhost; }
+  // global ids of the ghost columns, in local column order (local column = owned count + position)
+  std::vector<int64_t> const& ghostGids() const { return mGhostGids; }
+  // Setup-time ghost import of host data along the matrix' plan: one value per owned column in, one per ghost
+  // column out.  COLLECTIVE (an all-gather of the packed send sides; the device path is mxg_csr_apply's exchange).
+  template <typename T>
+  std::vector<T> importGhostsHost(std::vector<T> const& owned) const {
+    RCP<MxComm> comm = mRowMap->getComm();
+    const int me = comm->myPID(), np = comm->numProc();
+    std::vector<T> ghosts((size_t)mNumGhost);
+    if (np == 1) return ghosts;
+    // message: [nneigh, (peer, count) x nneigh] as int64, then the packed values
+    const size_t nn = mNeigh.size();
+    std::vector<char> msg(sizeof(int64_t) * (1 + 2 * nn) + sizeof(T) * mSendIdx.size());
+    int64_t* head = reinterpret_cast<int64_t*>(msg.data());
+    head[0] = (int64_t)nn;
+    for (size_t i = 0; i < nn; ++i) { head[1 + 2 * i] = mNeigh[i]; head[2 + 2 * i] = mSendOff[i + 1] - mSendOff[i]; }
+    T* pay = reinterpret_cast<T*>(msg.data() + sizeof(int64_t) * (1 + 2 * nn));
+    for (size_t i = 0; i < mSendIdx.size(); ++i) pay[i] = owned[(size_t)mSendIdx[i]];
+    std::vector<int64_t> counts(np, 0);
+    MX_ABI(mxg_comm_allgather_i64(comm->getCtx(), (int64_t)msg.size(), counts.data()), "MxCrsMatrix::importGhostsHost (sizes)");
+    int64_t total = 0;
+    std::vector<int64_t> off(np + 1, 0);
+    for (int r = 0; r < np; ++r) { off[r + 1] = off[r] + counts[r]; total += counts[r]; }
+    std::vector<char> all((size_t)total + 8);
+    MX_ABI(mxg_comm_allgatherv(comm->getCtx(), msg.data(), (int64_t)msg.size(), counts.data(), all.data()),
+           "MxCrsMatrix::importGhostsHost (exchange)");
+    for (size_t i = 0; i < nn; ++i) {
+      const int p = mNeigh[i];
+      const int64_t nrecv = mRecvOff[i + 1] - mRecvOff[i];
+      if (nrecv == 0) continue;
+      const char* m = all.data() + off[p];
+      int64_t h0;
+      std::memcpy(&h0, m, sizeof(int64_t));
+      int64_t skip = 0, cnt = -1;
+      for (int64_t j = 0; j < h0; ++j) {
+        int64_t peer, c;
+        std::memcpy(&peer, m + sizeof(int64_t) * (1 + 2 * j), sizeof(int64_t));
+        std::memcpy(&c, m + sizeof(int64_t) * (2 + 2 * j), sizeof(int64_t));
+        if (peer == me) { cnt = c; break; }
+        skip += c;
+      }
+      if (cnt != nrecv) { std::cout << "MxCrsMatrix::importGhostsHost: rank " << p << " sends " << cnt << " values, rank " << me << " expects " << nrecv << "\n"; throw 1; }
+      std::memcpy(ghosts.data() + mRecvOff[i], m + sizeof(int64_t) * (1 + 2 * h0) + sizeof(T) * skip, sizeof(T) * (size_t)nrecv);
+    }
+    return ghosts;
+  }
   // square part on the owned columns (the block a rank-local preconditioner works on)
   mx::Csr<Scalar> ownedBlock() const {
     mx::Csr<Scalar> b;
@@ -306,6 +355,7 @@ class MxCrsMatrix {
   int64_t mNoIdx = 0;
   std::vector<int> mNeigh;
   std::vector<int64_t> mSendOff, mSendIdx, mRecvOff;
+  std::vector<int64_t> mGhostGids;
   bool mFilled;
   RCP<MxMap> mRowMap, mColMap;
   std::vector<std::vector<std::pair<MxIndex, Scalar> > > mRows;

@@ -13,6 +13,7 @@
 #include <complex>
 
 #include "MxAnasaziMV.hpp"
+#include "MxDistMultigrid.h"
 #include "MxEMOps.h"
 #include "mx_mg.hpp"   // maxwell_amd/csrc/host
 #include "mxh.h"
@@ -131,7 +132,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mxg_solve_info info;
     auto t0 = std::chrono::steady_clock::now();
     // first inversion: (L - sigma M) bWork1 = y, to the unscaled true residual linTol
-    MX_ABI(solve(ctx, mShiftedVecLapl->getRawMatrix(), y2.raw(), bWork1->raw(), &info, mVecMg), "MxMagWaveOp::Apply (vecLapl solve)");
+    MX_ABI(solve(ctx, mShiftedVecLapl->getRawMatrix(), y2.raw(), bWork1->raw(), &info, vecMgHandle()), "MxMagWaveOp::Apply (vecLapl solve)");
     mNumVecLinIters += info.iters;
     mVecCumSolveTime += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (pid == 0 && verbose > 1)
@@ -143,7 +144,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
       mEMOps->getOp("divB")->apply(y2, *psiWork1);
       psiWork2->set(ScalarTraits<Scalar>::zero());
       t0 = std::chrono::steady_clock::now();
-      MX_ABI(solve(ctx, mScaLapl->getRawMatrix(), psiWork1->raw(), psiWork2->raw(), &info, mScaMg), "MxMagWaveOp::Apply (scaLapl solve)");
+      MX_ABI(solve(ctx, mScaLapl->getRawMatrix(), psiWork1->raw(), psiWork2->raw(), &info, scaMgHandle()), "MxMagWaveOp::Apply (scaLapl solve)");
       mNumScaLinIters += info.iters;
       mScaCumSolveTime += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (pid == 0 && verbose > 1) std::cout << "True residual of scalar Laplacian solve: " << info.true_res << "\n";
@@ -304,9 +305,20 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     const mx::YeeAssembler<double>& a = mSim->getAssembler();
     mxg_ctx* ctx = mBMap->getComm()->getCtx();
     if (mVecMg) mxh_mg_destroy(mVecMg);
+    static const bool blockMg = getenv("MXG_DIST_MG") && std::string(getenv("MXG_DIST_MG")) == "block";
+    if (mSim->isDistributed() && !blockMg) {
+      // the single-rank hierarchy, every level row-partitioned over the MxGridDomain boxes (MxDistMultigrid.h)
+      mVecDmg.reset(new MxDistMultigrid(mShiftedVecLapl, 3, a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9));
+      if (mHasCurlNull && !mScaDmg)
+        mScaDmg.reset(new MxDistMultigrid(mScaLapl, 1, a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9));
+      if (pid == 0 && verbose)
+        std::cout << "Multigrid on the decomposed grid: " << mVecDmg->numLevels() << " levels (vector), coarsest "
+                  << mVecDmg->globalRows(mVecDmg->numLevels() - 1) << " rows\n";
+      return;
+    }
     if (mSim->isDistributed()) {
-      // one hierarchy per rank on the block of its own columns (no communication inside the V-cycle): the
-      // preconditioner of the global solve is block-diagonal over the MxGridDomain boxes, symmetric like its blocks
+      // MXG_DIST_MG=block: one hierarchy per rank on the block of its own columns (no communication inside the
+      // V-cycle; block-diagonal preconditioner, inner iterations grow with the number of boxes)
       mVecMg = mxh_mg_build_gids(ctx, mShiftedVecLapl->ownedBlock(), a.ownedGids(a.bfield()), 3, a.config().n, 2000, levels,
                                  sweeps, 30, 0.85, 1.9);
       if (mHasCurlNull && !mScaMg)
@@ -319,9 +331,11 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
       mScaMg = mxh_mg_build(ctx, mScaLapl->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);
   }
 
-  int solve(mxg_ctx* ctx, mxg_csr* A, mxg_mv* b, mxg_mv* x, mxg_solve_info* info, mxh_mg* mg) const {
+  mxg_mg* vecMgHandle() const { return mVecDmg ? mVecDmg->handle() : (mVecMg ? mxh_mg_handle(mVecMg) : nullptr); }
+  mxg_mg* scaMgHandle() const { return mScaDmg ? mScaDmg->handle() : (mScaMg ? mxh_mg_handle(mScaMg) : nullptr); }
+  int solve(mxg_ctx* ctx, mxg_csr* A, mxg_mv* b, mxg_mv* x, mxg_solve_info* info, mxg_mg* mg) const {
     mxg_solve_opts o = mOpts;
-    o.mg = (mUseMg && mg) ? mxh_mg_handle(mg) : nullptr;
+    o.mg = (mUseMg && mg) ? mg : nullptr;
     if (o.precond == 3 && !o.mg) o.precond = 1;
     return mUseCg ? mxg_solve_cg(ctx, A, b, x, &o, info) : mxg_solve_gmres(ctx, A, b, x, &o, info);
   }
@@ -341,6 +355,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   bool mUseMg = false;
   mxh_mg* mVecMg = nullptr;
   mxh_mg* mScaMg = nullptr;
+  std::shared_ptr<MxDistMultigrid> mVecDmg, mScaDmg;   // decomposed grid: row-partitioned levels
   mxg_solve_opts mOpts;
   mutable int mNumVecLinIters, mNumScaLinIters, mNumApplies;
   mutable double mVecCumSolveTime, mScaCumSolveTime;

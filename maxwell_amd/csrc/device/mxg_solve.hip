@@ -255,8 +255,10 @@ extern "C" int mxg_mg_create(mxg_ctx* c, int nlevels, mxg_csr* const* A, mxg_csr
   mg->ctx = c; mg->nlevels = nlevels; mg->pre = pre; mg->post = post; mg->coarse = coarse;
   mg->omega = omega; mg->cscale = cscale;
   for (int l = 0; l < nlevels; ++l) {
-    MXG_CHECK(A[l] && !A[l]->is_complex && A[l]->nrows == A[l]->ncols_owned && A[l]->nghost == 0,
-              "mxg_mg_create: level %d must be a real square single-rank matrix", l);
+    // levels of a decomposed grid carry ghost columns: their products import them (mxg_csr_apply), the transfer
+    // operators stay rank-local because aggregates never straddle two MxGridDomain boxes
+    MXG_CHECK(A[l] && !A[l]->is_complex && A[l]->nrows == A[l]->ncols_owned,
+              "mxg_mg_create: level %d must be a real matrix, square on the owned columns", l);
     mg->A.push_back(A[l]);
     if (l + 1 < nlevels) {
       MXG_CHECK(P && R && P[l] && R[l], "mxg_mg_create: missing transfer operator at level %d", l);
