@@ -112,9 +112,3 @@ def test_decomposed_eigensolve_matches_single_rank(ctx, oracle_pillbox16, nranks
         assert abs(out[0][1]["vec_iters"] - st1["vec_iters"]) <= 0.05 * st1["vec_iters"] + 2
         assert abs(out[0][1]["sca_iters"] - st1["sca_iters"]) <= 0.05 * st1["sca_iters"] + 2
 
-
-def test_block_multigrid_variant(monkeypatch):
-    """MXG_DIST_MG=block (one hierarchy per box, no communication inside the V-cycle) is read once per process; here
-    only the documented meaning of the switch is pinned: the default is the row-partitioned hierarchy."""
-    import os
-    assert os.environ.get("MXG_DIST_MG", "") != "block"
