@@ -198,10 +198,10 @@ class MxCrsMatrix {
                           mHost.col.data(), reinterpret_cast<const double*>(mHost.val.data()),
                           ScalarTraits<Scalar>::isComplex, halo ? &plan : NULL, &mDev), "MxCrsMatrix::fillComplete");
     // structured operators stream 3 bytes per entry instead of 12 (mxg_csr_compress; bit-identical results);
-    // MXG_COMPRESS=0 keeps the plain CSR kernels.  Operators with ghost columns keep the CSR kernel, whose
-    // interior blocks overlap the halo exchange.
+    // MXG_COMPRESS=0 keeps the plain CSR kernels.  With ghost columns the blocks that reference none are ordered
+    // first and overlap the halo exchange, exactly as with the CSR kernel.
     static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
-    if (compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 4096 && mNumGhost == 0)
+    if (compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 4096)
       MX_ABI(mxg_csr_compress_from(mDev, mHost.rowptr.data(), mHost.col.data(),
                                    reinterpret_cast<const double*>(mHost.val.data()), NULL, NULL, NULL),
              "MxCrsMatrix::fillComplete (compress)");

@@ -601,7 +601,9 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
 struct CsDesc {
   long long base;   // rowptr[r0]
   long long soff;   // byte offset of the block's packed stream (16-byte aligned); -1: plain CSR block
-  int r0, nr, nnzb, nval;
+  int r0, nrnv, nnzb, rb;   // nrnv = rows (<= 256) | distinct values << 16; rb = position of the block's row offsets in roff[]
+  __host__ __device__ inline int nr() const { return nrnv & 0xffff; }
+  __host__ __device__ inline int nval() const { return nrnv >> 16; }
 };
 static_assert(sizeof(CsDesc) == 32, "descriptor layout");
 constexpr int CS_SEGS = 16, CS_OFFBITS = 12, CS_MAXVAL = 256;
@@ -632,13 +634,17 @@ __device__ inline double cs_epilogue(double ax, long long row, const double* __r
 constexpr int CS_RPT = 2;
 // One column per launch (a block of k vectors is k launches: the packed stream is cheap to re-read, and
 // the single-column body keeps 16 waves per CU resident).
-template <typename CFG, int CH, bool DOT, int EPI = 0>
+// HALO: columns >= nowned are ghosts, read from xg[] (the receive buffer of the exchange); the blocks of a
+// row-partitioned matrix that reference none are ordered first and launched without it while the halo is in flight.
+template <typename CFG, int CH, bool DOT, int EPI = 0, bool HALO = false>
 __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     const CsDesc* __restrict__ desc, long long nblocks, const unsigned char* __restrict__ stream,
     const unsigned short* __restrict__ roff, const int* __restrict__ colidx, const double* __restrict__ vals,
     const double* __restrict__ x, double* __restrict__ y,
     const double* __restrict__ xdot, double* __restrict__ partial,
-    const double* __restrict__ rhs, const double* __restrict__ diag, double omega) {
+    const double* __restrict__ rhs, const double* __restrict__ diag, double omega,
+    const double* __restrict__ xg, long long nowned) {
+  auto xat = [&](int cc) -> double { return (HALO && cc >= nowned) ? xg[cc - nowned] : x[cc]; };
   constexpr int RPT = CS_RPT, SB = CFG::SBLK / RPT;
   __shared__ __attribute__((aligned(16))) unsigned short scode[CFG::NNZ_BLK];
   __shared__ __attribute__((aligned(16))) unsigned char svid[CFG::NNZ_BLK];
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
   if (d.nnzb > CFG::NNZ_CAP) {     // one over-long row: whole workgroup, fixed-order combine (as k_spmv_rowgather)
     double sr = 0.0;
 #pragma unroll 1
-    for (long long q = d.base + t; q < d.base + d.nnzb; q += SB) sr += vals[q] * x[colidx[q]];
+    for (long long q = d.base + t; q < d.base + d.nnzb; q += SB) sr += vals[q] * xat(colidx[q]);
     svtab[t] = sr;
     __syncthreads();
     if (t == 0) {
@@ -670,8 +676,8 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     if (t < CS_SEGS) sseg[t] = nt_load(reinterpret_cast<const int*>(sp) + t);
     const double* vt = reinterpret_cast<const double*>(sp + CS_SEGS * 4);
 #pragma unroll 1
-    for (int p = t; p < d.nval; p += SB) svtab[p] = nt_load(vt + p);
-    const int nvpad = (d.nval + 1) & ~1;
+    for (int p = t; p < d.nval(); p += SB) svtab[p] = nt_load(vt + p);
+    const int nvpad = (d.nval() + 1) & ~1;
     const uint4v* cp = reinterpret_cast<const uint4v*>(sp + CS_SEGS * 4 + nvpad * 8);
     const int ncode16 = (d.nnzb + 7) >> 3;            // 16-byte pieces of the code array (8 codes each)
 #pragma unroll 1
@@ -685,8 +691,8 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
   for (int r = 0; r < RPT; ++r) {
     const int row = t + r * SB;
     o0[r] = 0; o1[r] = 0;
-    if (row < d.nr) {
-      const unsigned short* ro = roff + d.r0 + b + row;
+    if (row < d.nr()) {
+      const unsigned short* ro = roff + d.rb + row;
       o0[r] = ro[0];
       o1[r] = ro[1];
     }
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
         const unsigned code = on ? scode[o0[r] + i] : 0u;
         const int cc = on ? sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u)) : 0;
         v[r][i] = on ? svtab[svid[o0[r] + i]] : 0.0;
-        xv[r][i] = on ? x[cc] : 0.0;
+        xv[r][i] = on ? xat(cc) : 0.0;
       }
     }
 #pragma unroll
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
 #pragma unroll 1
       for (int q = o0[r] + CH; q < o1[r]; ++q) {       // longer rows: the tail, in storage order
         const unsigned code = scode[q];
-        sum[r] += svtab[svid[q]] * x[sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u))];
+        sum[r] += svtab[svid[q]] * xat(sseg[code >> CS_OFFBITS] + (int)(code & ((1u << CS_OFFBITS) - 1u)));
       }
     }
   } else {
@@ -724,14 +730,14 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     for (int r = 0; r < RPT; ++r) {
       sum[r] = 0.0;
 #pragma unroll 1
-      for (long long q = d.base + o0[r]; q < d.base + o1[r]; ++q) sum[r] += vals[q] * x[colidx[q]];
+      for (long long q = d.base + o0[r]; q < d.base + o1[r]; ++q) sum[r] += vals[q] * xat(colidx[q]);
     }
   }
   double part = 0.0;
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
     const int row = t + r * SB;
-    if (row < d.nr) {
+    if (row < d.nr()) {
       __builtin_nontemporal_store(cs_epilogue<EPI>(sum[r], d.r0 + row, x, rhs, diag, omega, y), y + d.r0 + row);
       if (DOT) part += sum[r] * xdot[d.r0 + row];
     }
@@ -1144,10 +1150,11 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
     std::vector<uint64_t> w;
     for (size_t b = b0; b < b1; ++b) {
       CsDesc d{};
-      d.r0 = blk[b]; d.nr = blk[b + 1] - blk[b];
+      d.r0 = blk[b]; d.nrnv = blk[b + 1] - blk[b];
       d.base = rp[blk[b]];
       d.nnzb = (int)(rp[blk[b + 1]] - d.base);
-      d.soff = -1; d.nval = 0;
+      d.soff = -1;
+      d.rb = d.r0 + (int)b;
       desc[b] = d;
       if (d.nnzb > RgCfgA::NNZ_CAP || d.nnzb == 0) continue;
       // column bands: greedy cover of the sorted distinct columns with windows of 2^12
@@ -1188,7 +1195,7 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
         std::memcpy(&bits, va + d.base + q, sizeof bits);
         vid[q] = (unsigned char)(std::lower_bound(w.begin(), w.end(), bits) - w.begin());
       }
-      desc[b].nval = nval;
+      desc[b].nrnv |= nval << 16;
       desc[b].soff = 0;   // final offset assigned below
     }
   };
@@ -1209,6 +1216,19 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
   std::vector<unsigned char> stream(total + 16, 0);
   for (size_t b = 0; b < nb; ++b)
     if (desc[b].soff >= 0) std::memcpy(stream.data() + desc[b].soff, packs[b].data(), packs[b].size());
+  a->ncs_interior = (int64_t)nb;
+  if (a->nghost > 0) {
+    // row-partitioned matrix: blocks that touch no ghost column first - they run while the halo is in flight
+    std::vector<CsDesc> inner, outer;
+    for (const CsDesc& d : desc) {
+      bool ghost = false;
+      for (long long q = d.base; q < d.base + d.nnzb && !ghost; ++q) ghost = ci[q] >= a->ncols_owned;
+      (ghost ? outer : inner).push_back(d);
+    }
+    a->ncs_interior = (int64_t)inner.size();
+    desc = inner;
+    desc.insert(desc.end(), outer.begin(), outer.end());
+  }
   if (a->d_csdesc) hipFree(a->d_csdesc);
   if (a->d_csstream) hipFree(a->d_csstream);
   MXG_HIP(hipMalloc(&a->d_csdesc, sizeof(CsDesc) * std::max<size_t>(nb, 1)));
@@ -1396,6 +1416,35 @@ static int launch_rowgather_halo(mxg_ctx* c, mxg_csr* a, const MvDesc& X, const 
   return 0;
 }
 
+// compressed-stream kernel on a row-partitioned matrix (real, one column): interior blocks, wait for the halo,
+// boundary blocks with ghost reads.  halo_start(c, a, x) must have been called.
+template <bool DOT, int EPI>
+static int launch_cs_halo(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const double* xdot, double* partial,
+                          const double* rhs, const double* diag, double omega) {
+  const CsDesc* desc = (const CsDesc*)a->d_csdesc;
+  const long long ni = a->ncs_interior, nb = a->ncs - a->ncs_interior;
+  if (ni > 0) {
+    const unsigned grid = (unsigned)(((ni + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
+    hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, DOT, EPI, false>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream, desc, ni,
+                       (const unsigned char*)a->d_csstream, (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, x, y,
+                       xdot, partial, rhs, diag, omega, (const double*)nullptr, 0LL);
+  }
+  MXG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+  if (nb > 0) {
+    const unsigned grid = (unsigned)(((nb + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
+    hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, DOT, EPI, true>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream, desc + ni, nb,
+                       (const unsigned char*)a->d_csstream, (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, x, y,
+                       xdot, DOT ? partial + ni : partial, rhs, diag, omega, (const double*)a->d_ghost, (long long)a->ncols_owned);
+  }
+  MXG_HIP(hipGetLastError());
+  return 0;
+}
+
+static inline bool cs_halo_ok(const mxg_csr* a, const mxg_mv* x, const mxg_mv* y) {
+  return (a->kernel & 0x1000000) && !a->is_complex && a->ncs > 0 && a->pipe_geo == 10 && x->k == 1 && y->k == 1 &&
+         x->base != y->base && (a->nghost > 0 || a->nneigh > 0);
+}
+
 extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg_mv* y) {
   mxg_csr* a = const_cast<mxg_csr*>(a_);
   MXG_CHECK(c && a && x && y, "mxg_csr_apply: NULL argument");
@@ -1409,6 +1458,12 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
   MvDesc X = x->desc();
   const MvDesc Y = y->desc();
   const bool halo = a->nghost > 0 || a->nneigh > 0;
+  if (cs_halo_ok(a, x, y)) {
+    MXG_TRY(halo_start(c, a, x));
+    if (a->nrows == 0) { MXG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0)); return 0; }
+    (void)hipGetLastError();
+    return launch_cs_halo<false, 0>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, nullptr, nullptr, 0.0);
+  }
   if (halo && !a->is_complex && a->pipe_geo == 10 && a->npipe > 0 && (a->kernel & 0x1030000) == 0x10000 &&
       !(a->kernel & 0xC0C0) && x->base != y->base) {
     // default kernel on a distributed matrix: overlapped ghost import, owned x read in place
@@ -1443,7 +1498,8 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
       hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
                          (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
                          (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(j), Y.col(j),
-                         (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0);
+                         (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0,
+                         (const double*)nullptr, 0LL);
   } else if ((a->kernel & 0x30000) && !a->is_complex && a->npipe > 0) {
     const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
@@ -1519,6 +1575,16 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
 // Returns 1 without touching y when the matrix is not compressed (the caller takes the unfused path).
 int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
                           const double* diag, double omega) {
+  if (cs_halo_ok(a, x, y) && epi != 3) {
+    if (halo_start(c, a, x) != 0) return 2;
+    if (a->nrows == 0) { hipStreamWaitEvent(c->stream, c->ev_halo, 0); return 0; }
+    (void)hipGetLastError();
+    int rc;
+    if (epi == 1) rc = launch_cs_halo<false, 1>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
+    else if (epi == 2) rc = launch_cs_halo<false, 2>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
+    else rc = launch_cs_halo<false, 0>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
+    return rc == 0 ? 0 : 2;
+  }
   if (!((a->kernel & 0x1000000) && !a->is_complex && a->ncs > 0 && a->pipe_geo == 10 && a->nghost == 0 &&
         a->nneigh == 0 && x->k == 1 && y->k == 1 && x->base != y->base))
     return 1;
@@ -1530,7 +1596,7 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
   hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false, E>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,     \
                      (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,        \
                      (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0), \
-                     (const double*)nullptr, (double*)nullptr, rhs, diag, omega)
+                     (const double*)nullptr, (double*)nullptr, rhs, diag, omega, (const double*)nullptr, 0LL)
   if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else if (epi == 3) MXG_CS_EPI(3); else MXG_CS_EPI(0);
 #undef MXG_CS_EPI
   if (hipGetLastError() != hipSuccess) { mxg_set_error("mxg_dev_csr_apply_epi: launch failed"); return 2; }
@@ -1549,6 +1615,10 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
   if (a->nghost > 0 || a->nneigh > 0) {
     MXG_TRY(halo_start(c, a, x));
     (void)hipGetLastError();
+    if (cs_halo_ok(a, x, y) && a->ncs == a->npipe)
+      MXG_TRY((launch_cs_halo<true, 0>(c, a, x->colptr(0), y->colptr(0), (const double*)x->colptr(0), a->d_dotpartial,
+                                       nullptr, nullptr, 0.0)));
+    else
     MXG_TRY((launch_rowgather_halo<true>(c, a, X, Y, (const double*)x->colptr(0), a->d_dotpartial)));
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, (const double*)a->d_dotpartial,
                        (long long)a->npipe, d_out);
@@ -1562,7 +1632,8 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
     hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
                        (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
                        (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0),
-                       (const double*)x->colptr(0), a->d_dotpartial, (const double*)nullptr, (const double*)nullptr, 0.0);
+                       (const double*)x->colptr(0), a->d_dotpartial, (const double*)nullptr, (const double*)nullptr, 0.0,
+                       (const double*)nullptr, 0LL);
   else
   hipLaunchKernelGGL((k_spmv_rowgather<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,
                      (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr,

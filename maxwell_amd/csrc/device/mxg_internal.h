@@ -135,6 +135,7 @@ struct mxg_csr {
   void* d_csdesc = nullptr;
   unsigned char* d_csstream = nullptr;
   int64_t ncs = 0, cs_fallback = 0, cs_bytes = 0;
+  int64_t ncs_interior = 0;      // compressed descriptors [0, ncs_interior) reference no ghost column
   // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
   void* d_xwdesc = nullptr;
   unsigned short* d_lcol = nullptr;

@@ -208,6 +208,11 @@ class DistMatrix:
     def apply_bytes(self, k=1):
         return self.ctx.lib.mxg_csr_apply_bytes(self.h, k)
 
+    def compress(self):
+        nb, nf, sb = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(self.ctx.lib.mxg_csr_compress(self.h, C.byref(nb), C.byref(nf), C.byref(sb)), self.ctx.lib)
+        return nb.value, nf.value, sb.value
+
 
 def bench_setup(ctx, n_local, shift):
     """Weak-scaling workload of bench.py: the pillbox cavity of example/pillbox.py on a grid refined so
