@@ -16,6 +16,7 @@
 #include <array>
 
 #include "MxCrsMatrix.hpp"
+#include "mx_mg.hpp"   // maxwell_amd/csrc/host
 #include "mxh.h"
 
 class MxDistMultigrid {
@@ -37,7 +38,12 @@ class MxDistMultigrid {
     mA.push_back(A0);
     int64_t dims[3] = {n[0] + 1, n[1] + 1, n[2] + 1};
     int level = 0;
-    while ((int)mA.size() < maxLevels && (int64_t)mA.back()->getRangeMap()->getGlobalNumIndices() > minCoarse) {
+    // levels above this many global rows are row-partitioned; below, the hierarchy continues replicated on every
+    // rank (one all-gather per V-cycle instead of a latency-bound ghost import per sweep and level)
+    int64_t replicateBelow = 100000;
+    if (const char* e = getenv("MXG_DIST_MG_REPLICATE")) replicateBelow = atoll(e);
+    while ((int)mA.size() < maxLevels &&
+           (int64_t)mA.back()->getRangeMap()->getGlobalNumIndices() > std::max(minCoarse, replicateBelow)) {
       bool aligned = true;
       for (int r = 0; r < np; ++r)
         for (int i = 0; i < 3; ++i) aligned = aligned && (boxLo[r][i] % (1 << (level + 1)) == 0);
@@ -52,10 +58,15 @@ class MxDistMultigrid {
     for (auto& m : mR) r.push_back(m->getRawMatrix());
     MX_ABI(mxg_mg_create(comm->getCtx(), (int)a.size(), a.data(), p.data(), r.data(), sweeps, sweeps, coarseSweeps, omega,
                          coarseScale, &mMg), "MxDistMultigrid");
+    if (np > 1) replicateTail(dims, minCoarse, maxLevels - (int)mA.size() + 1, sweeps, coarseSweeps, omega, coarseScale);
   }
-  ~MxDistMultigrid() { if (mMg) mxg_mg_destroy(mMg); }
+  ~MxDistMultigrid() {
+    if (mMg) mxg_mg_destroy(mMg);
+    if (mTail) mxh_mg_destroy(mTail);
+  }
   mxg_mg* handle() const { return mMg; }
   int numLevels() const { return (int)mA.size(); }
+  int numReplicatedLevels() const { return mTailLevels; }
   int64_t globalRows(int l) const { return (int64_t)mA[l]->getRangeMap()->getGlobalNumIndices(); }
 
  private:
@@ -184,6 +195,84 @@ class MxDistMultigrid {
     return true;
   }
 
+  // The last row-partitioned level gathered on every rank (rows in rank order, so a rank's own rows are one
+  // segment), continued by the single-rank builder; the device cycle gathers that level's right-hand side once.
+  void replicateTail(const int64_t dims[3], int64_t minCoarse, int maxLevels, int sweeps, int coarseSweeps, double omega,
+                     double coarseScale) {
+    RCP<MxCrsMatrix<double> > Al = mA.back();
+    RCP<MxMap> map = Al->getRangeMap();
+    RCP<MxComm> comm = map->getComm();
+    const int np = comm->numProc();
+    const mx::Csr<double>& A = Al->getHostCsr();
+    const int64_t nr = A.nrows, nnz = A.nnz(), nown = nr;
+    const std::vector<int64_t>& ghosts = Al->ghostGids();
+    // message (int64 words): rows, entries, row ids, row pointers, column ids, value bit patterns
+    std::vector<int64_t> msg((size_t)(2 + nr + (nr + 1) + 2 * nnz));
+    size_t w = 0;
+    msg[w++] = nr; msg[w++] = nnz;
+    for (int64_t i = 0; i < nr; ++i) msg[w++] = (int64_t)map->getGlobalIndex((MxIndex)i);
+    for (int64_t i = 0; i <= nr; ++i) msg[w++] = A.rowptr[i];
+    for (int64_t q = 0; q < nnz; ++q) msg[w++] = A.col[q] < nown ? (int64_t)map->getGlobalIndex((MxIndex)A.col[q]) : ghosts[A.col[q] - nown];
+    for (int64_t q = 0; q < nnz; ++q) { int64_t bits; std::memcpy(&bits, &A.val[q], sizeof bits); msg[w++] = bits; }
+    std::vector<int64_t> counts(np, 0);
+    MX_ABI(mxg_comm_allgather_i64(comm->getCtx(), (int64_t)(msg.size() * sizeof(int64_t)), counts.data()), "MxDistMultigrid (tail sizes)");
+    int64_t total = 0;
+    for (int r = 0; r < np; ++r) total += counts[r] / (int64_t)sizeof(int64_t);
+    std::vector<int64_t> all((size_t)total + 1);
+    MX_ABI(mxg_comm_allgatherv(comm->getCtx(), msg.data(), (int64_t)(msg.size() * sizeof(int64_t)), counts.data(), all.data()),
+           "MxDistMultigrid (tail gather)");
+    // pass 1: row ids in gathered order
+    std::vector<int64_t> rowsOf(np), off(np + 1, 0);
+    mx::UVec<int64_t> gids;
+    int64_t nnzAll = 0;
+    {
+      size_t p = 0;
+      for (int r = 0; r < np; ++r) {
+        const int64_t n_r = all[p], z_r = all[p + 1];
+        rowsOf[r] = n_r; off[r + 1] = off[r] + n_r; nnzAll += z_r;
+        for (int64_t i = 0; i < n_r; ++i) gids.push_back(all[p + 2 + i]);
+        p += (size_t)(2 + n_r + (n_r + 1) + 2 * z_r);
+      }
+    }
+    const int64_t nAll = off[np];
+    std::vector<std::pair<int64_t, int64_t> > lookup((size_t)nAll);
+    for (int64_t i = 0; i < nAll; ++i) lookup[i] = std::make_pair(gids[i], i);
+    std::sort(lookup.begin(), lookup.end());
+    mx::Csr<double> G;
+    G.nrows = nAll; G.ncols = nAll;
+    G.rowptr.resize(nAll + 1);
+    G.col.resize(nnzAll); G.val.resize(nnzAll);
+    G.rowptr[0] = 0;
+    {
+      size_t p = 0;
+      int64_t row = 0, q0 = 0;
+      for (int r = 0; r < np; ++r) {
+        const int64_t n_r = all[p], z_r = all[p + 1];
+        const int64_t* rp = &all[p + 2 + n_r];
+        const int64_t* ck = rp + (n_r + 1);
+        const int64_t* vb = ck + z_r;
+        for (int64_t i = 0; i < n_r; ++i) G.rowptr[row + i + 1] = q0 + rp[i + 1];
+        for (int64_t q = 0; q < z_r; ++q) {
+          auto it = std::lower_bound(lookup.begin(), lookup.end(), std::make_pair(ck[q], (int64_t)-1));
+          if (it == lookup.end() || it->first != ck[q]) { std::cout << "MxDistMultigrid: column " << ck[q] << " of the gathered level has no row\n"; throw 1; }
+          G.col[q0 + q] = (int32_t)it->second;
+          std::memcpy(&G.val[q0 + q], &vb[q], sizeof(double));
+        }
+        row += n_r; q0 += z_r;
+        p += (size_t)(2 + n_r + (n_r + 1) + 2 * z_r);
+      }
+    }
+    const int nl[3] = {(int)dims[0] - 1, (int)dims[1] - 1, (int)dims[2] - 1};
+    mTail = mxh_mg_build_gids(comm->getCtx(), G, gids, mNcomp, nl, minCoarse, std::max(maxLevels, 1), sweeps, coarseSweeps,
+                              omega, coarseScale);
+    int nlev = 0;
+    mxh_mg_level_sizes(mTail, nullptr, nullptr, &nlev);
+    mTailLevels = nlev;
+    MX_ABI(mxg_mg_set_tail(mMg, mxh_mg_handle(mTail), rowsOf.data()), "MxDistMultigrid (tail)");
+  }
+
+  mxh_mg* mTail = nullptr;
+  int mTailLevels = 0;
   int mNcomp;
   int mN[3];
   int mProcGrid[3] = {1, 1, 1};

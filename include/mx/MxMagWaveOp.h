@@ -312,8 +312,8 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
       if (mHasCurlNull && !mScaDmg)
         mScaDmg.reset(new MxDistMultigrid(mScaLapl, 1, a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9));
       if (pid == 0 && verbose)
-        std::cout << "Multigrid on the decomposed grid: " << mVecDmg->numLevels() << " levels (vector), coarsest "
-                  << mVecDmg->globalRows(mVecDmg->numLevels() - 1) << " rows\n";
+        std::cout << "Multigrid on the decomposed grid: " << mVecDmg->numLevels() << " row-partitioned levels (vector), then "
+                  << mVecDmg->numReplicatedLevels() << " replicated from " << mVecDmg->globalRows(mVecDmg->numLevels() - 1) << " rows\n";
       return;
     }
     if (mSim->isDistributed()) {

@@ -186,6 +186,11 @@ int mxg_mg_create(mxg_ctx* ctx, int nlevels, mxg_csr* const* A, mxg_csr* const* 
 int mxg_mg_destroy(mxg_mg* mg);
 /* z = M^-1 r (one column), one V-cycle */
 int mxg_mg_apply(mxg_ctx* ctx, mxg_mg* mg, const mxg_mv* r, mxg_mv* z);
+/* Decomposed grid: below the last row-partitioned level the hierarchy continues REPLICATED on every rank.
+ * `tail` is a single-rank hierarchy whose level 0 is the last level of `mg` gathered over the ranks in rank order
+ * (counts[r] = rows of rank r); per V-cycle one all-gather of that level's right-hand side replaces the ghost
+ * imports of every sweep on every level below (they are latency-bound there).  `tail` stays owned by the caller. */
+int mxg_mg_set_tail(mxg_mg* mg, mxg_mg* tail, const int64_t* counts);
 
 typedef struct mxg_solve_opts {
   double tol;          /* unscaled true-residual 2-norm target (AZ_noscaled, :346,352) */

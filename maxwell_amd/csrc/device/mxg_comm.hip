@@ -133,6 +133,26 @@ int mxg_comm_exchange(mxg_ctx* c, const MxgXfer* x, int n, hipStream_t s) {
   return 0;
 }
 
+int mxg_comm_allgather_dev(mxg_ctx* c, const double* send, size_t n, double* recv, hipStream_t s) {
+  if (c->comm) {
+    MXG_NCCL(ncclAllGather(send, recv, n, ncclDouble, c->comm, s));
+    return 0;
+  }
+  mxg_local_world* w = c->lw;
+  if (!w) {
+    MXG_HIP(hipMemcpyAsync(recv, send, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  MXG_HIP(hipStreamSynchronize(s));
+  w->gptr[c->rank] = send;
+  MXG_LW_BARRIER(w);
+  for (int r = 0; r < w->n; ++r)
+    MXG_HIP(hipMemcpyAsync(recv + n * r, w->gptr[r], sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  MXG_HIP(hipStreamSynchronize(s));
+  MXG_LW_BARRIER(w);
+  return 0;
+}
+
 extern "C" int mxg_comm_allgather_i64(mxg_ctx* c, int64_t v, int64_t* out) {
   MXG_CHECK(c && out, "mxg_comm_allgather_i64: NULL argument");
   if (!mxg_comm_on(c)) { out[0] = v; return 0; }

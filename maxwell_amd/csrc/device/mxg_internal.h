@@ -165,6 +165,8 @@ struct MxgXfer { int peer; const double* send; int64_t ns; double* recv; int64_t
 bool mxg_comm_on(const mxg_ctx* c);
 int mxg_comm_allreduce(mxg_ctx* c, double* d, size_t count, hipStream_t s);
 int mxg_comm_exchange(mxg_ctx* c, const MxgXfer* x, int n, hipStream_t s);
+// recv[r * n .. r * n + n) = send[0 .. n) of rank r (device buffers, equal counts)
+int mxg_comm_allgather_dev(mxg_ctx* c, const double* send, size_t n, double* recv, hipStream_t s);
 
 // reductions / workspace helpers (mxg_ctx.hip)
 int mxg_ctx_reserve_reduce(mxg_ctx* ctx, size_t width);

@@ -160,6 +160,12 @@ struct mxg_mg {
                                       // ping-pong partner of z for the fused sweeps)
   int pre = 2, post = 2, coarse = 20;
   double omega = 0.7, cscale = 1.9;
+  // decomposed grid: replicated continuation below the last row-partitioned level (mxg_mg_set_tail)
+  mxg_mg* tail = nullptr;
+  std::vector<int64_t> tail_counts;
+  int64_t tail_pad = 0, tail_off = 0;
+  double* d_gsend = nullptr;
+  double* d_grecv = nullptr;
 };
 
 namespace {
@@ -217,9 +223,33 @@ int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
   return 0;
 }
 
+int mg_cycle(mxg_mg* mg, int l);
+
+// last row-partitioned level: gather its right-hand side, run the replicated levels, keep the own segment
+int mg_tail(mxg_mg* mg, int l) {
+  mxg_ctx* c = mg->ctx;
+  mxg_mg* t = mg->tail;
+  const int64_t nown = mg->A[l]->nrows;
+  if (nown > 0)
+    MXG_HIP(hipMemcpyAsync(mg->d_gsend, mg->r[l]->colptr(0), sizeof(double) * nown, hipMemcpyDeviceToDevice, c->stream));
+  MXG_TRY(mxg_comm_allgather_dev(c, mg->d_gsend, (size_t)mg->tail_pad, mg->d_grecv, c->stream));
+  int64_t off = 0;
+  for (size_t r = 0; r < mg->tail_counts.size(); ++r) {
+    if (mg->tail_counts[r] > 0)
+      MXG_HIP(hipMemcpyAsync(t->r[0]->colptr(0) + off, mg->d_grecv + mg->tail_pad * (int64_t)r,
+                             sizeof(double) * mg->tail_counts[r], hipMemcpyDeviceToDevice, c->stream));
+    off += mg->tail_counts[r];
+  }
+  MXG_TRY(mg_cycle(t, 0));
+  if (nown > 0)
+    MXG_HIP(hipMemcpyAsync(mg->z[l]->colptr(0), t->z[0]->colptr(0) + mg->tail_off, sizeof(double) * nown,
+                           hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
 int mg_cycle(mxg_mg* mg, int l) {
   mxg_ctx* c = mg->ctx;
-  if (l == mg->nlevels - 1) return mg_smooth(mg, l, mg->coarse, true);
+  if (l == mg->nlevels - 1) return mg->tail ? mg_tail(mg, l) : mg_smooth(mg, l, mg->coarse, true);
   const long long n = mg->A[l]->nrows;
   const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
   MXG_TRY(mg_smooth(mg, l, mg->pre, true));
@@ -277,8 +307,33 @@ extern "C" int mxg_mg_create(mxg_ctx* c, int nlevels, mxg_csr* const* A, mxg_csr
   return 0;
 }
 
+extern "C" int mxg_mg_set_tail(mxg_mg* mg, mxg_mg* tail, const int64_t* counts) {
+  MXG_CHECK(mg && tail && counts, "mxg_mg_set_tail: NULL argument");
+  mxg_ctx* c = mg->ctx;
+  int64_t total = 0, mx = 0;
+  mg->tail_counts.assign(counts, counts + c->nranks);
+  for (int r = 0; r < c->nranks; ++r) {
+    if (r == c->rank) mg->tail_off = total;
+    total += counts[r];
+    mx = std::max(mx, counts[r]);
+  }
+  MXG_CHECK(counts[c->rank] == mg->A.back()->nrows && total == tail->A[0]->nrows,
+            "mxg_mg_set_tail: the replicated level has %lld rows, the ranks hold %lld (this rank %lld of %lld)",
+            (long long)tail->A[0]->nrows, (long long)total, (long long)counts[c->rank], (long long)mg->A.back()->nrows);
+  mg->tail_pad = std::max<int64_t>((mx + 31) & ~(int64_t)31, 32);
+  if (mg->d_gsend) hipFree(mg->d_gsend);
+  if (mg->d_grecv) hipFree(mg->d_grecv);
+  MXG_HIP(hipMalloc(&mg->d_gsend, sizeof(double) * mg->tail_pad));
+  MXG_HIP(hipMalloc(&mg->d_grecv, sizeof(double) * mg->tail_pad * c->nranks));
+  MXG_HIP(hipMemsetAsync(mg->d_gsend, 0, sizeof(double) * mg->tail_pad, c->stream));
+  mg->tail = tail;
+  return 0;
+}
+
 extern "C" int mxg_mg_destroy(mxg_mg* mg) {
   if (!mg) return 0;
+  if (mg->d_gsend) hipFree(mg->d_gsend);
+  if (mg->d_grecv) hipFree(mg->d_grecv);
   for (auto* v : mg->r) mxg_mv_destroy(v);
   for (auto* v : mg->z) mxg_mv_destroy(v);
   for (auto* v : mg->t) mxg_mv_destroy(v);
