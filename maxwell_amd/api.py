@@ -326,10 +326,11 @@ class Sim:
     """Grid + BCs + PEC shape -> assembled operators (MxEMSim::setup + MxEMOps + initMatrices)."""
 
     def __init__(self, n, origin=(0.0, 0.0, 0.0), size=(1.0, 1.0, 1.0), lower=("periodic",) * 3,
-                 upper=("periodic",) * 3, pec_shape=None, strict=True, dielectrics=None, dm_frac=0.0):
+                 upper=("periodic",) * 3, pec_shape=None, strict=True, dielectrics=None, dm_frac=0.0, box=None):
         """dielectrics: list of (eps, shape_spec[, loss_tangent]); eps = 3 diagonal numbers, or 6 (diag + the
         deck's `eps off diag` triple), or a scalar for an isotropic material.  A loss tangent makes the problem
-        complex: its operators come from Problem.op, not from Sim."""
+        complex: its operators come from Problem.op, not from Sim.
+        box: (lo, hi) cell box of this rank on a decomposed grid (maxwell_amd.distributed.BoxSim)."""
         self.lib = _lib.load_mxhost()
         n = [int(n)] * 3 if np.ndim(n) == 0 else [int(v) for v in n]
         self.n = n
@@ -339,6 +340,8 @@ class Sim:
         lo = (C.c_char_p * 3)(*[s.encode() for s in lower])
         up = (C.c_char_p * 3)(*[s.encode() for s in upper])
         h = C.c_void_p()
+        blo = (C.c_int * 3)(*box[0]) if box is not None else None
+        bhi = (C.c_int * 3)(*box[1]) if box is not None else None
         dspec = None
         if dielectrics:
             items = []
@@ -349,7 +352,7 @@ class Sim:
                 items.append(",".join(repr(v) for v in e) + (" tan=%r" % tan if tan else "") + " : " + shape)
             dspec = " | ".join(items).encode()
         _chk(self.lib.mxh_sim_create_ex(nn, oo, ss, lo, up, pec_shape.encode() if pec_shape else None, dspec,
-                                        float(dm_frac), int(bool(strict)), None, None, C.byref(h)), self.lib, "mxh")
+                                        float(dm_frac), int(bool(strict)), blo, bhi, C.byref(h)), self.lib, "mxh")
         self.h = h
 
     @classmethod

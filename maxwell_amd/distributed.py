@@ -51,22 +51,13 @@ class BoxSim(Sim):
     """Sim restricted to the cell box of one rank."""
 
     def __init__(self, n, rank, nranks, origin=(0.0, 0.0, 0.0), size=(1.0, 1.0, 1.0),
-                 lower=("periodic",) * 3, upper=("periodic",) * 3, pec_shape=None, strict=True):
-        self.lib = _lib.load_mxhost()
+                 lower=("periodic",) * 3, upper=("periodic",) * 3, pec_shape=None, strict=True, dielectrics=None,
+                 dm_frac=0.0):
         n = [int(n)] * 3 if np.ndim(n) == 0 else [int(v) for v in n]
-        self.n, self.rank, self.nranks = n, rank, nranks
+        self.rank, self.nranks = rank, nranks
         self.proc_grid, self.box_lo, self.box_hi = partition(n, nranks, rank)
-        nn = (C.c_int * 3)(*n)
-        oo = (C.c_double * 3)(*origin)
-        ss = (C.c_double * 3)(*size)
-        lo = (C.c_char_p * 3)(*[s.encode() for s in lower])
-        up = (C.c_char_p * 3)(*[s.encode() for s in upper])
-        blo = (C.c_int * 3)(*self.box_lo)
-        bhi = (C.c_int * 3)(*self.box_hi)
-        h = C.c_void_p()
-        _chk(self.lib.mxh_sim_create_box(nn, oo, ss, lo, up, pec_shape.encode() if pec_shape else None,
-                                         int(bool(strict)), blo, bhi, C.byref(h)), self.lib, "mxh")
-        self.h = h
+        Sim.__init__(self, n, origin=origin, size=size, lower=lower, upper=upper, pec_shape=pec_shape, strict=strict,
+                     dielectrics=dielectrics, dm_frac=dm_frac, box=(self.box_lo, self.box_hi))
 
     def dist_op(self, name, shift=0.0):
         """Owned rows with GLOBAL column ids: dict(rowptr, colgid, vals, rowgid, colowned, ncomp)."""
