@@ -316,7 +316,22 @@ class MxProblem {
     if (!gridSet) getGrid(XMLNode());
     if (!bcSet) getBCs(XMLNode());
     cfg.strict = mStrict;
-    if (!comm.is_null()) sim = rcp(new MxEMSim<DIM>(cfg, comm, pList));
+    if (comm.is_null()) return;
+    if (comm->numProc() > 1) {
+      // one rank per MxGridDomain box (src/MxGrid.cpp:171-193): assemble this rank's box + halo window and form the
+      // operator chain on it; MxEMSim / MxMagWaveOp take the owned rows from there (real problems)
+      int pg[3];
+      if (mxh_partition(cfg.n, comm->numProc(), comm->myPID(), pg, cfg.boxLo, cfg.boxHi) != 0)
+        throw std::runtime_error("MxProblem: MxGrid::partition failed");
+      if (pList.get("is complex", false))
+        throw std::runtime_error("MxProblem: complex problems (phase shifts, loss tangents) run on one rank in this build");
+      mBoxAsm = std::make_shared<mx::YeeAssembler<double> >(cfg);
+      mBoxOps = mBoxAsm->waveOps();
+      sim = rcp(new MxEMSim<DIM>(cfg, comm, pList, mBoxAsm));
+      sim->setPrebuiltOps(&mBoxOps);
+      return;
+    }
+    sim = rcp(new MxEMSim<DIM>(cfg, comm, pList));
   }
 
   // reference main(): `prob3d = new MxProblem<3>(xmlObj, myComm); prob3d->solve();`
@@ -331,6 +346,7 @@ class MxProblem {
     }
   }
   bool isComplex() const { return pList.get("is complex", false); }
+  std::vector<MxComplex> const& eigenvalues() const { return isComplex() ? csolver->eigenvalues() : solver->eigenvalues(); }
   std::vector<MxComplex> const& frequencies() const { return isComplex() ? csolver->frequencies() : solver->frequencies(); }
   std::vector<double> const& residuals() const { return isComplex() ? csolver->residuals() : solver->residuals(); }
 
@@ -609,6 +625,8 @@ class MxProblem {
   mx::YeeConfig cfg;
   Teuchos::ParameterList pList;
   std::vector<std::shared_ptr<mx::Shape> > shapes;
+  std::shared_ptr<mx::YeeAssembler<double> > mBoxAsm;      // decomposed grid: this rank's window assembler and
+  typename MxEMSim<DIM>::OpCache mBoxOps;                  // its operator chain (outlive sim / solver: declared first)
   RCP<MxEMSim<DIM> > sim;
   RCP<MxSolver<DIM, double> > solver;
   RCP<MxSolver<DIM, MxComplex> > csolver;

@@ -159,6 +159,17 @@ extern "C" int mxh_problem_solver(mxg_ctx* ctx, mxh_problem* p, int verbose, mxh
     s->precType = pl.get("linear solver : prec type", "none");
     if (p->prob->isComplex()) {
       mxh_solver_build_complex(*s, ctx, p->prob->getConfig(), pl);
+    } else if (mxg_ctx_nranks(ctx) > 1) {
+      // decomposed grid: this rank's MxGridDomain box of the deck's grid (src/MxGrid.cpp:171-193)
+      std::shared_ptr<mxh_sim> box(new mxh_sim());
+      box->cfg = p->prob->getConfig();
+      int pg[3];
+      if (mxh_partition(box->cfg.n, mxg_ctx_nranks(ctx), mxg_ctx_rank(ctx), pg, box->cfg.boxLo, box->cfg.boxHi) != 0) return 1;
+      box->asmb.reset(new mx::YeeAssembler<double>(box->cfg));
+      box->ops = box->asmb->waveOps();
+      box->mask = box->asmb->usedMask();
+      s->ownSim = box;
+      mxh_solver_build(*s, ctx, box.get(), pl);
     } else {
       mxh_sim* sim = nullptr;
       if (mxh_problem_sim(p, &sim) != 0) return 1;

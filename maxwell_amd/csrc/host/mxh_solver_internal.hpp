@@ -10,6 +10,7 @@
 #include "mxh_internal.hpp"
 
 struct mxh_solver {
+  std::shared_ptr<mxh_sim> ownSim;                         // box simulation made for this solver (declared first: destroyed last)
   RCP<MxComm> comm;
   RCP<MxEMSim<3> > sim;
   std::unique_ptr<MxSolver<3, double> > solver;            // real problems

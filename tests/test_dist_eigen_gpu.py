@@ -144,3 +144,53 @@ def test_decomposed_dielectric_sphere_non_hermitian(ctx):
         assert max(abs(r["k2"].imag) for r in out[0]) < 1e-9
         for res in out[1:]:
             assert [r["k2"] for r in res] == [r["k2"] for r in out[0]]
+
+
+def test_deck_on_a_decomposed_grid(ctx, tmp_path):
+    """A `.mx` deck on 2 boxes through both entries: mxh_problem_solver (Problem.solver on rank contexts) and the C++
+    MxProblem<3> as the `maxwell` command line drives it per process (tests/cpp/test_problem_ranks.cpp: rank
+    threads of an in-process world); same eigenvalues as the single-rank run of the deck."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    deck = os.path.join(root, "tests", "golden", "pillbox.mx")
+    one = mx.Problem(path=deck).solver(ctx)
+    n1 = one.solve()
+    k1 = np.sort([one.result(i)["k2"].real for i in range(n1)])
+    shift = float(mx.Problem(path=deck).param("eigensolver : shift"))
+
+    def rank(c):
+        s = mx.Problem(path=deck).solver(c)
+        n = s.solve()
+        return [s.result(i)["k2"].real for i in range(n)]
+
+    out = _run_ranks(2, rank)
+    assert out[0] == out[1] and len(out[0]) == n1
+    tol = 50 * float(mx.Problem(path=deck).param("eigensolver : tol"))
+    assert np.abs(np.sort(out[0]) - k1).max() / np.abs(k1).max() < tol
+
+    exe = str(tmp_path / "test_problem_ranks")
+    lib = os.path.join(root, "maxwell_amd", "lib")
+    subprocess.run(["g++", "-O1", "-fopenmp", "-std=c++17", "-I" + os.path.join(root, "include"),
+                    "-I" + os.path.join(root, "include", "mx"), "-I" + os.path.join(root, "maxwell_amd", "csrc", "host"),
+                    os.path.join(root, "tests", "cpp", "test_problem_ranks.cpp"), "-o", exe, "-L" + lib, "-lmxhost", "-lmxg",
+                    "-lpthread", "-Wl,-rpath," + lib], check=True)
+    r = subprocess.run([exe, deck, "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    theta = [float(line.split()[2]) for line in r.stdout.splitlines() if line.startswith("THETA")]
+    k2 = np.sort([1.0 / t + shift for t in theta])
+    assert len(k2) == n1 and np.abs(k2 - k1).max() / np.abs(k1).max() < tol, (k2, k1)
+
+
+def test_maxwell_cli_with_rccl_id_file(built, tmp_path):
+    """`maxwell` under a launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK + --id-file): the unique-id hand-over
+    and the RCCL communicator, here with a world of one process (RCCL refuses two ranks on the one test GPU)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    idf = tmp_path / "rccl.id"
+    r = subprocess.run([os.path.join(root, "maxwell_amd", "lib", "maxwell"), "--infile=" + os.path.join(root, "tests", "golden", "pillbox.mx"),
+                        "--no-fields", "--id-file=" + str(idf)], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "========= Eigenfrequencies (Hz) =========" in r.stdout and not idf.exists()
