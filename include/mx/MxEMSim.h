@@ -62,13 +62,14 @@ class MxEMSim {
   // A problem with Bloch phase shifts (src/MxGridField.cpp:34-38,157-188) or lossy dielectrics is assembled in complex arithmetic;
   // everything else in real arithmetic.
   MxEMSim(mx::YeeConfig const& cfg, RCP<MxComm> comm, Teuchos::ParameterList pList = Teuchos::ParameterList(),
-          std::shared_ptr<mx::YeeAssembler<double> > assembler = nullptr)
+          std::shared_ptr<mx::YeeAssembler<double> > assembler = nullptr,
+          std::shared_ptr<mx::YeeAssembler<MxComplex> > complexAssembler = nullptr)
       : mCfg(cfg), mGrid(comm), mPList(pList) {
     static_assert(DIM == 3, "only the 3-D path is built");
     mComplex = cfg.phaseShifts[0] != 0.0 || cfg.phaseShifts[1] != 0.0 || cfg.phaseShifts[2] != 0.0;
     for (auto const& dl : cfg.dielectrics) if (dl.lossy()) mComplex = true;   // loss tangent, src/MxProblem.cpp:507-508
     if (mComplex) {
-      mAsmC = std::make_shared<mx::YeeAssembler<MxComplex> >(cfg);
+      mAsmC = complexAssembler ? complexAssembler : std::make_shared<mx::YeeAssembler<MxComplex> >(cfg);
       addFields(*mAsmC, comm);
     } else {
       mAsm = assembler ? assembler : std::make_shared<mx::YeeAssembler<double> >(cfg);
@@ -83,9 +84,13 @@ class MxEMSim {
   // operators already assembled for this configuration (the mxh_sim of the C ABI computes the whole chain for
   // export); MxMagWaveOp::initMatrices adopts them instead of repeating the products.  Real problems only.
   typedef std::map<std::string, mx::Csr<double> > OpCache;
+  typedef std::map<std::string, mx::Csr<MxComplex> > OpCacheC;
   void setPrebuiltOps(const OpCache* ops) { mPrebuilt = ops; }
+  void setPrebuiltOps(const OpCacheC* ops) { mPrebuiltC = ops; }
   const OpCache* prebuiltOps(double*) const { return mPrebuilt; }
-  const OpCache* prebuiltOps(MxComplex*) const { return nullptr; }
+  const OpCacheC* prebuiltOps(MxComplex*) const { return mPrebuiltC; }
+  // complex problem on a decomposed grid: the window assembler is shared with whoever formed the operator chain
+  void setComplexAssembler(std::shared_ptr<mx::YeeAssembler<MxComplex> > a) { mAsmC = a; }
   bool hasPEC() const { return (bool)mCfg.pec; }
   bool hasDielectric() const { return !mCfg.dielectrics.empty(); }
   bool hasMu() const { return false; }
@@ -167,6 +172,7 @@ class MxEMSim {
   bool mWindowed = false;
   int mProcGrid[3] = {1, 1, 1};
   const OpCache* mPrebuilt = nullptr;
+  const OpCacheC* mPrebuiltC = nullptr;
   std::shared_ptr<mx::YeeAssembler<double> > mAsm;
   mutable std::shared_ptr<mx::YeeAssembler<MxComplex> > mAsmC;
   std::map<std::string, std::shared_ptr<MxGridField<DIM> > > mFields;

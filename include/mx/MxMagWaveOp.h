@@ -172,19 +172,19 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   static MxComplex toScalarImpl(std::complex<double> z, MxComplex*) { return z; }
   static Scalar toScalar(std::complex<double> z) { return toScalarImpl(z, (Scalar*)0); }
 
-  RCP<MxCrsMatrix<Scalar> > shiftedDistributed(Scalar, MxComplex*) { return RCP<MxCrsMatrix<Scalar> >(); }
-  RCP<MxCrsMatrix<Scalar> > shiftedDistributed(Scalar newShift, double*) {
-    const typename MxEMSim<DIM>::OpCache* pre = mSim->prebuiltOps((double*)0);
-    const mx::YeeAssembler<double>& a = mSim->getAssembler();
-    mx::Csr<double> sh = mx::add(pre->at("vecLapl"), 1.0, pre->at("mRhs"), -newShift);
+  template <typename S2>
+  RCP<MxCrsMatrix<Scalar> > shiftedDistributed(Scalar newShift, S2*) {
+    auto pre = mSim->prebuiltOps((Scalar*)0);
+    const mx::YeeAssembler<Scalar>& a = mSim->assemblerFor((Scalar*)0);
+    mx::Csr<Scalar> sh = mx::add(pre->at("vecLapl"), ScalarTraits<Scalar>::one(), pre->at("mRhs"), -newShift);
     return mEMOps->distributed(mBMap, mBMap, a.bfield(), a.bfield(), sh);
   }
 
   void initMatrices() {   // :138-245
     if (adoptPrebuilt((Scalar*)0)) return;
     if (mSim->isDistributed()) {
-      std::cout << "MxMagWaveOp: a decomposed grid needs the real operator chain formed on the box + halo window "
-                   "(MxEMSim::setPrebuiltOps); complex problems are single-rank for now\n";
+      std::cout << "MxMagWaveOp: a decomposed grid needs the operator chain formed on the box + halo window "
+                   "(MxEMSim::setPrebuiltOps)\n";
       throw 1;
     }
     mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim));
@@ -226,9 +226,9 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   }
 
   // the operator chain was already formed for this configuration (mxh_sim): adopt it, same matrices bit for bit
-  bool adoptPrebuilt(MxComplex*) { return false; }
-  bool adoptPrebuilt(double*) {
-    const typename MxEMSim<DIM>::OpCache* pre = mSim->prebuiltOps((double*)0);
+  template <typename S2>
+  bool adoptPrebuilt(S2*) {
+    auto pre = mSim->prebuiltOps((Scalar*)0);
     if (!pre || !pre->count("vecLapl") || !pre->count("scaLapl") || !pre->count("mRhs")) return false;
     mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim, false));
     for (auto const& e : *pre) mEMOps->adopt(e.first, e.second);

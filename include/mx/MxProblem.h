@@ -323,8 +323,13 @@ class MxProblem {
       int pg[3];
       if (mxh_partition(cfg.n, comm->numProc(), comm->myPID(), pg, cfg.boxLo, cfg.boxHi) != 0)
         throw std::runtime_error("MxProblem: MxGrid::partition failed");
-      if (pList.get("is complex", false))
-        throw std::runtime_error("MxProblem: complex problems (phase shifts, loss tangents) run on one rank in this build");
+      if (pList.get("is complex", false)) {
+        mBoxAsmC = std::make_shared<mx::YeeAssembler<MxComplex> >(cfg);
+        mBoxOpsC = mBoxAsmC->waveOps();
+        sim = rcp(new MxEMSim<DIM>(cfg, comm, pList, nullptr, mBoxAsmC));
+        sim->setPrebuiltOps(&mBoxOpsC);
+        return;
+      }
       mBoxAsm = std::make_shared<mx::YeeAssembler<double> >(cfg);
       mBoxOps = mBoxAsm->waveOps();
       sim = rcp(new MxEMSim<DIM>(cfg, comm, pList, mBoxAsm));
@@ -627,6 +632,8 @@ class MxProblem {
   std::vector<std::shared_ptr<mx::Shape> > shapes;
   std::shared_ptr<mx::YeeAssembler<double> > mBoxAsm;      // decomposed grid: this rank's window assembler and
   typename MxEMSim<DIM>::OpCache mBoxOps;                  // its operator chain (outlive sim / solver: declared first)
+  std::shared_ptr<mx::YeeAssembler<MxComplex> > mBoxAsmC;  // the same for complex decks
+  typename MxEMSim<DIM>::OpCacheC mBoxOpsC;
   RCP<MxEMSim<DIM> > sim;
   RCP<MxSolver<DIM, double> > solver;
   RCP<MxSolver<DIM, MxComplex> > csolver;

@@ -25,7 +25,18 @@ void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::Parame
 void mxh_solver_build_complex(mxh_solver& s, mxg_ctx* ctx, mx::YeeConfig const& cfg, Teuchos::ParameterList const& pl) {
   s.comm = rcp(new MxComm(ctx));
   s.params.shift = pl.get("eigensolver : shift", 0.0);
-  s.sim = rcp(new MxEMSim<3>(cfg, s.comm, pl));
+  if (s.comm->numProc() > 1) {
+    // decomposed grid: this rank's box of the grid, complex window assembly and operator chain
+    mx::YeeConfig box = cfg;
+    int pg[3];
+    if (mxh_partition(box.n, s.comm->numProc(), s.comm->myPID(), pg, box.boxLo, box.boxHi) != 0) throw std::runtime_error(mxh_last_error());
+    s.boxAsmC = std::make_shared<mx::YeeAssembler<MxComplex> >(box);
+    s.boxOpsC = s.boxAsmC->waveOps();
+    s.sim = rcp(new MxEMSim<3>(box, s.comm, pl, nullptr, s.boxAsmC));
+    s.sim->setPrebuiltOps(&s.boxOpsC);
+  } else {
+    s.sim = rcp(new MxEMSim<3>(cfg, s.comm, pl));
+  }
   s.csolver.reset(new MxSolver<3, MxComplex>(s.sim, pl));
 }
 

@@ -11,6 +11,8 @@
 
 struct mxh_solver {
   std::shared_ptr<mxh_sim> ownSim;                         // box simulation made for this solver (declared first: destroyed last)
+  std::shared_ptr<mx::YeeAssembler<MxComplex> > boxAsmC;   // complex problem on a decomposed grid: window assembler + chain
+  MxEMSim<3>::OpCacheC boxOpsC;
   RCP<MxComm> comm;
   RCP<MxEMSim<3> > sim;
   std::unique_ptr<MxSolver<3, double> > solver;            // real problems

@@ -194,3 +194,32 @@ def test_maxwell_cli_with_rccl_id_file(built, tmp_path):
                         "--no-fields", "--id-file=" + str(idf)], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "========= Eigenfrequencies (Hz) =========" in r.stdout and not idf.exists()
+
+
+def test_complex_decks_on_a_decomposed_grid(ctx):
+    """Complex arithmetic on 2 boxes: (a) the Bloch-phase fibre deck (strict=False) - ghost
+    columns across the periodic seam carry e^{+-i phi}; (b) the lossy dielectric sphere (complex FIT inverse
+    permittivity, complex eigenvalues).  Same eigenvalues as the single-rank complex solve."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fiber = open(os.path.join(root, "tests", "golden", "fiber.mx")).read()
+    lossy = open(os.path.join(root, "tests", "golden", "dsphmsph.mx")).read().replace(
+        "eps off diag = [0.0, 0.0, 0.0]", "eps off diag = [0.0, 0.0, 0.0]\n    loss tangent = 0.001").replace(
+        "resolution = [12, 12, 12]", "resolution = [10, 10, 10]").replace("type = amg", "type = ilu")
+    for text, strict, want in ((fiber, False, 4), (lossy, True, 3)):
+        one = mx.Problem(text=text, strict=strict)
+        assert one.is_complex
+        s1 = one.solver(ctx)
+        assert s1.solve() == want
+        k1 = np.array(sorted((s1.result(i)["k2"] for i in range(want)), key=lambda z: (round(z.real, 6), z.imag)))
+
+        def rank(c):
+            s = mx.Problem(text=text, strict=strict).solver(c)
+            n = s.solve()
+            return [s.result(i)["k2"] for i in range(n)]
+
+        out = _run_ranks(2, rank)
+        assert out[0] == out[1] and len(out[0]) == want
+        k2 = np.array(sorted(out[0], key=lambda z: (round(z.real, 6), z.imag)))
+        tol = 50 * float(one.param("eigensolver : tol"))
+        assert np.abs(k2 - k1).max() / np.abs(k1).max() < tol, (k2, k1)
