@@ -5,7 +5,7 @@
 // Differences from the reference binary: no MPI::Init - one process drives one GPU.  Started N times by any launcher
 // that sets RANK / WORLD_SIZE / LOCAL_RANK (torchrun's convention; `mpirun` users export them from their own rank
 // variables), the processes share the RCCL unique id through the file named by --id-file (or MXG_ID_FILE): rank 0
-// writes it, the others wait for it, and the deck is solved on a decomposed grid, one MxGridDomain box per process
+// writes it, the others wait for it, and the deck is solved on a decomposed grid, one MxGridDomain box per process.
 // 1-D/2-D decks are rejected instead of instantiated; the
 // eigenvector files of MxIO::save are written as HDF5 when a libhdf5 can be loaded at run time and as
 // `.npy` otherwise; `--eigvals=FILE` additionally writes the frequencies as text.
