@@ -288,29 +288,47 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mOpts.restart = linBasis;
     mOpts.max_iters = mPList.get("linear solver : max iters", 0);
     mOpts.cheb_degree = 0; mOpts.lmin = 0; mOpts.lmax = 0; mOpts.mg = nullptr;
-    if (mUseMg) {
-      if (ScalarTraits<Scalar>::isComplex) {
-        if (pid == 0) std::cout << "MxMagWaveOp: multigrid is real for now -> Jacobi.\n";
-        mOpts.precond = 1; mUseMg = false;
-      } else {
-        buildMultigrid((Scalar*)0);
-      }
-    }
+    if (mUseMg) buildMultigrid((Scalar*)0);
   }
 
-  void buildMultigrid(MxComplex*) {}
-  void buildMultigrid(double*) {
+  // the matrix the hierarchy is built from: the operator itself, or the real part of a complex operator (Bloch
+  // phases touch the seam entries only, loss tangents are small: its V-cycle, applied to the real and the
+  // imaginary part of a residual in turn, preconditions the complex solve - mxg_mg_apply)
+  static RCP<MxCrsMatrix<double> > realPart(RCP<MxCrsMatrix<double> > m) { return m; }
+  static RCP<MxCrsMatrix<double> > realPart(RCP<MxCrsMatrix<MxComplex> > m) {
+    const mx::Csr<MxComplex>& c = m->getHostCsr();
+    if (!m->isDistributed()) {
+      mx::Csr<double> r;
+      r.nrows = c.nrows; r.ncols = c.ncols; r.rowptr = c.rowptr; r.col = c.col;
+      r.val.resize(c.val.size());
+      for (size_t q = 0; q < c.val.size(); ++q) r.val[q] = c.val[q].real();
+      return rcp(new MxCrsMatrix<double>(m->getRangeMap(), m->getDomainMap(), r));
+    }
+    // row-partitioned: global column ids again, the real matrix agrees its own ghost import (collective)
+    const int64_t nown = c.ncols - m->numGhosts();
+    mx::UVec<int64_t> colg(c.col.size());
+    mx::UVec<double> val(c.val.size());
+    for (size_t q = 0; q < c.col.size(); ++q) {
+      colg[q] = c.col[q] < nown ? (int64_t)m->getDomainMap()->getGlobalIndex((MxIndex)c.col[q]) : m->ghostGids()[c.col[q] - nown];
+      val[q] = c.val[q].real();
+    }
+    return rcp(new MxCrsMatrix<double>(m->getRangeMap(), m->getDomainMap(), c.rowptr, colg, val));
+  }
+
+  void buildMultigrid(Scalar*) {
     const int sweeps = mPList.get("linear solver : amg : sweeps", 2);
     const int levels = mPList.get("linear solver : amg : max levels", 10);
-    const mx::YeeAssembler<double>& a = mSim->getAssembler();
+    const mx::YeeAssembler<Scalar>& a = mSim->assemblerFor((Scalar*)0);
     mxg_ctx* ctx = mBMap->getComm()->getCtx();
     if (mVecMg) mxh_mg_destroy(mVecMg);
+    mVecMgMatrix = realPart(mShiftedVecLapl);
+    if (mHasCurlNull && mScaMgMatrix.is_null()) mScaMgMatrix = realPart(mScaLapl);
     static const bool blockMg = getenv("MXG_DIST_MG") && std::string(getenv("MXG_DIST_MG")) == "block";
     if (mSim->isDistributed() && !blockMg) {
       // the single-rank hierarchy, every level row-partitioned over the MxGridDomain boxes (MxDistMultigrid.h)
-      mVecDmg.reset(new MxDistMultigrid(mShiftedVecLapl, 3, a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9));
+      mVecDmg.reset(new MxDistMultigrid(mVecMgMatrix, 3, a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9));
       if (mHasCurlNull && !mScaDmg)
-        mScaDmg.reset(new MxDistMultigrid(mScaLapl, 1, a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9));
+        mScaDmg.reset(new MxDistMultigrid(mScaMgMatrix, 1, a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9));
       if (pid == 0 && verbose)
         std::cout << "Multigrid on the decomposed grid: " << mVecDmg->numLevels() << " row-partitioned levels (vector), then "
                   << mVecDmg->numReplicatedLevels() << " replicated from " << mVecDmg->globalRows(mVecDmg->numLevels() - 1) << " rows\n";
@@ -319,16 +337,16 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     if (mSim->isDistributed()) {
       // MXG_DIST_MG=block: one hierarchy per rank on the block of its own columns (no communication inside the
       // V-cycle; block-diagonal preconditioner, inner iterations grow with the number of boxes)
-      mVecMg = mxh_mg_build_gids(ctx, mShiftedVecLapl->ownedBlock(), a.ownedGids(a.bfield()), 3, a.config().n, 2000, levels,
+      mVecMg = mxh_mg_build_gids(ctx, mVecMgMatrix->ownedBlock(), a.ownedGids(a.bfield()), 3, a.config().n, 2000, levels,
                                  sweeps, 30, 0.85, 1.9);
       if (mHasCurlNull && !mScaMg)
-        mScaMg = mxh_mg_build_gids(ctx, mScaLapl->ownedBlock(), a.ownedGids(a.psifield()), 1, a.config().n, 2000, levels,
+        mScaMg = mxh_mg_build_gids(ctx, mScaMgMatrix->ownedBlock(), a.ownedGids(a.psifield()), 1, a.config().n, 2000, levels,
                                    sweeps, 30, 0.85, 1.9);
       return;
     }
-    mVecMg = mxh_mg_build(ctx, mShiftedVecLapl->getHostCsr(), a.bfield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);
+    mVecMg = mxh_mg_build(ctx, mVecMgMatrix->getHostCsr(), a.bfield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);
     if (mHasCurlNull && !mScaMg)
-      mScaMg = mxh_mg_build(ctx, mScaLapl->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);
+      mScaMg = mxh_mg_build(ctx, mScaMgMatrix->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9);
   }
 
   mxg_mg* vecMgHandle() const { return mVecDmg ? mVecDmg->handle() : (mVecMg ? mxh_mg_handle(mVecMg) : nullptr); }
@@ -356,6 +374,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   mxh_mg* mVecMg = nullptr;
   mxh_mg* mScaMg = nullptr;
   std::shared_ptr<MxDistMultigrid> mVecDmg, mScaDmg;   // decomposed grid: row-partitioned levels
+  RCP<MxCrsMatrix<double> > mVecMgMatrix, mScaMgMatrix; // what the hierarchies are built from (real part if complex)
   mxg_solve_opts mOpts;
   mutable int mNumVecLinIters, mNumScaLinIters, mNumApplies;
   mutable double mVecCumSolveTime, mScaCumSolveTime;

@@ -341,10 +341,36 @@ extern "C" int mxg_mg_destroy(mxg_mg* mg) {
   return 0;
 }
 
+namespace {
+// part 0 / 1 of an interleaved complex vector -> real vector, and back
+__global__ void k_cplx_take(long long n, const double* __restrict__ zc, int part, double* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = zc[2 * i + part];
+}
+__global__ void k_cplx_put(long long n, const double* __restrict__ in, int part, double* __restrict__ zc) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) zc[2 * i + part] = in[i];
+}
+}  // namespace
+
 extern "C" int mxg_mg_apply(mxg_ctx* c, mxg_mg* mg, const mxg_mv* r, mxg_mv* z) {
   MXG_CHECK(c && mg && r && z, "mxg_mg_apply: NULL argument");
-  MXG_CHECK(r->k == 1 && z->k == 1 && r->nlocal == mg->A[0]->nrows && z->nlocal == r->nlocal && !r->is_complex,
-            "mxg_mg_apply: shape mismatch");
+  MXG_CHECK(r->k == 1 && z->k == 1 && r->nlocal == mg->A[0]->nrows && z->nlocal == r->nlocal &&
+            r->is_complex == z->is_complex, "mxg_mg_apply: shape mismatch");
+  if (r->is_complex) {
+    // real hierarchy (of the real part of a complex operator) on a complex residual: one cycle per part
+    const long long n = r->nlocal;
+    const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
+    for (int part = 0; part < 2; ++part) {
+      hipLaunchKernelGGL(k_cplx_take, dim3(grid), dim3(256), 0, c->stream, n, (const double*)r->colptr(0), part,
+                         mg->r[0]->colptr(0));
+      MXG_TRY(mg_cycle(mg, 0));
+      hipLaunchKernelGGL(k_cplx_put, dim3(grid), dim3(256), 0, c->stream, n, (const double*)mg->z[0]->colptr(0), part,
+                         z->colptr(0));
+    }
+    MXG_HIP(hipGetLastError());
+    return 0;
+  }
   MXG_TRY(mxg_mv_copy(mg->r[0], r));
   MXG_TRY(mg_cycle(mg, 0));
   return mxg_mv_copy(z, mg->z[0]);
