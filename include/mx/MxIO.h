@@ -35,17 +35,43 @@ class MxIO {
     const size_t total = (size_t)(dims[0] * dims[1] * dims[2] * dims[3]);
     const MxMap& map = *field.getMap();
     const size_t nloc = map.getNodeNumIndices();
-    std::vector<Scalar> col;
-    std::vector<double> re(total), im;
-    if (ScalarTraits<Scalar>::isComplex) im.resize(total);
+    // decomposed grid: rank 0 collects every rank's (global id, value) pairs and writes the whole lattice, like the
+    // single file per vector the reference's parallel HDF5 write produces (src/MxIO.cpp:167-222)
+    const int np = mComm->numProc(), me = mComm->myPID();
+    std::vector<int64_t> gids(nloc), counts(np, 0), allGids;
+    for (size_t l = 0; l < nloc; ++l) gids[l] = (int64_t)map.getGlobalIndex(l);
+    if (np > 1) {
+      MX_ABI(mxg_comm_allgather_i64(mComm->getCtx(), (int64_t)(nloc * sizeof(int64_t)), counts.data()), "MxIO::save (sizes)");
+      size_t tot = 0;
+      for (int r = 0; r < np; ++r) tot += (size_t)counts[r] / sizeof(int64_t);
+      allGids.resize(tot + 1);
+      MX_ABI(mxg_comm_allgatherv(mComm->getCtx(), gids.data(), (int64_t)(nloc * sizeof(int64_t)), counts.data(), allGids.data()),
+             "MxIO::save (ids)");
+      allGids.resize(tot);
+    }
+    std::vector<Scalar> col, allVals;
+    std::vector<double> re, im;
+    if (me == 0) { re.resize(total); if (ScalarTraits<Scalar>::isComplex) im.resize(total); }
     for (size_t vec = 0; vec < fieldData.getNumVecs(); ++vec) {
       fieldData.getColumn(vec, col);
+      const std::vector<int64_t>* ids = &gids;
+      const std::vector<Scalar>* vals = &col;
+      if (np > 1) {
+        std::vector<int64_t> vcounts(np);
+        for (int r = 0; r < np; ++r) vcounts[r] = counts[r] / (int64_t)sizeof(int64_t) * (int64_t)sizeof(Scalar);
+        allVals.resize(allGids.size() + 1);
+        MX_ABI(mxg_comm_allgatherv(mComm->getCtx(), col.data(), (int64_t)(nloc * sizeof(Scalar)), vcounts.data(), allVals.data()),
+               "MxIO::save (values)");
+        allVals.resize(allGids.size());
+        ids = &allGids; vals = &allVals;
+      }
+      if (me != 0) continue;
       std::fill(re.begin(), re.end(), 0.0);
       std::fill(im.begin(), im.end(), 0.0);
-      for (size_t l = 0; l < nloc; ++l) {
-        const size_t g = (size_t)map.getGlobalIndex(l);
-        re[g] = mxRe(col[l]);
-        if (ScalarTraits<Scalar>::isComplex) im[g] = mxIm(col[l]);
+      for (size_t l = 0; l < ids->size(); ++l) {
+        const size_t g = (size_t)(*ids)[l];
+        re[g] = mxRe((*vals)[l]);
+        if (ScalarTraits<Scalar>::isComplex) im[g] = mxIm((*vals)[l]);
       }
       char stem[256], written[512];
       std::snprintf(stem, sizeof stem, "mx%s_%s_vec%.2i", field.getFieldName().c_str(), name.c_str(), (int)vec);

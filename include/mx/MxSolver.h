@@ -99,7 +99,7 @@ class MxSolver {
     mwOpPtr->magToElec(*mBEigVecs, *mEEigVecs);
     // src/MxSolver.cpp:222-224: the reference always writes the fields; here on request ("io : save fields",
     // set by the `maxwell` command line) - 3 (N+1)^3 doubles per vector is 0.4 GB at 256^3
-    if (pList.get("io : save fields", false) && sim->getGrid().getComm()->numProc() == 1) {
+    if (pList.get("io : save fields", false)) {
       MxIO<DIM, Scalar> io(sim->getGrid().getComm());
       std::vector<std::string> fb = io.save(*mBEigVecs, sim->getField("bfield"), "eigVecs");
       std::vector<std::string> fe = io.save(*mEEigVecs, sim->getField("efield"), "eigVecs");

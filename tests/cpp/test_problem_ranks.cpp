@@ -1,7 +1,7 @@
 // The reference's main() on a decomposed grid: `MxProblem<3> prob(xml, comm); prob.solve();` on R ranks, each
 // rank a thread of this process with its own context of an in-process world (mxg_local_world) - what
 // `maxwell --infile=deck.mx` does per process under a launcher.  Prints the k^2 of rank 0 and checks that every
-// rank holds the same eigenvalues.   usage: test_problem_ranks deck.mx R
+// rank holds the same eigenvalues.   usage: test_problem_ranks deck.mx R [save]   (save: write the field files)
 #include <cstdio>
 #include <thread>
 
@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
       try {
         RCP<MxComm> comm = rcp(new MxComm(ctx));
         MxProblem<3> prob(xml, comm, true);
+        prob.setSaveFields(argc > 3);
         prob.solve();
         ev[r] = prob.eigenvalues();
       } catch (const std::exception& e) {

@@ -175,11 +175,37 @@ def test_deck_on_a_decomposed_grid(ctx, tmp_path):
                     "-I" + os.path.join(root, "include", "mx"), "-I" + os.path.join(root, "maxwell_amd", "csrc", "host"),
                     os.path.join(root, "tests", "cpp", "test_problem_ranks.cpp"), "-o", exe, "-L" + lib, "-lmxhost", "-lmxg",
                     "-lpthread", "-Wl,-rpath," + lib], check=True)
-    r = subprocess.run([exe, deck, "2"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, deck, "2", "save"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     theta = [float(line.split()[2]) for line in r.stdout.splitlines() if line.startswith("THETA")]
     k2 = np.sort([1.0 / t + shift for t in theta])
     assert len(k2) == n1 and np.abs(k2 - k1).max() / np.abs(k1).max() < tol, (k2, k1)
+    # rank 0 wrote whole-lattice eigenvector files (MxIO::save gathers the boxes): same layout as the single-rank
+    # file, the lowest mode equal to the single-rank eigenvector up to sign
+
+    def read_field(path):
+        if path.endswith(".npy"):
+            return np.load(path)
+        import ctypes as C
+        from maxwell_amd import _lib
+        lib = _lib.load_mxhost()
+        dims = (C.c_int64 * 4)()
+        n = mx.Problem(path=deck).grid()["n"]
+        arr = np.empty((n[0] + 1) * (n[1] + 1) * (n[2] + 1) * 3)
+        assert lib.mxh_field_read_h5(path.encode(), b"real", dims, arr.ctypes.data_as(_lib.c_dp), arr.size) == 0
+        return arr.reshape(tuple(dims))
+
+    v1 = one.eigvec(int(np.argmin([one.result(i)["k2"].real for i in range(n1)])), mx.Problem(path=deck).sim().map("bfield").size)
+    gids = mx.Problem(path=deck).sim().map("bfield")
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("mxYeeFitBField_eigVecs_vec"))
+    assert len(files) == n1
+    order = np.argsort([1.0 / t + shift for t in theta])
+    arr = read_field(os.path.join(str(tmp_path), files[int(order[0])]))
+    flat = arr.reshape(-1)
+    assert np.count_nonzero(flat) <= len(gids) and np.abs(np.delete(flat, gids)).max() == 0.0
+    got = flat[gids]
+    got, v1 = got / np.linalg.norm(got), v1 / np.linalg.norm(v1)
+    assert min(np.abs(got - v1).max(), np.abs(got + v1).max()) < 1e-4
 
 
 def test_maxwell_cli_with_rccl_id_file(built, tmp_path):
