@@ -91,6 +91,7 @@ MXG_SIGNATURES = {
                                 C.c_double, C.c_double, C.POINTER(vp)]),
     "mxg_mg_destroy": (C.c_int, [vp]),
     "mxg_mg_apply": (C.c_int, [vp, vp, vp, vp]),
+    "mxg_mg_set_tail": (C.c_int, [vp, vp, c_i64p]),
     "mxg_solve_cg": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "mxg_solve_gmres": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
 }
