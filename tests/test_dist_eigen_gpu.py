@@ -249,3 +249,25 @@ def test_complex_decks_on_a_decomposed_grid(ctx):
         k2 = np.array(sorted(out[0], key=lambda z: (round(z.real, 6), z.imag)))
         tol = 50 * float(one.param("eigensolver : tol"))
         assert np.abs(k2 - k1).max() / np.abs(k1).max() < tol, (k2, k1)
+
+
+@pytest.mark.parametrize("n,nranks", [([14, 11, 9], 3), ([20, 12, 10], 6)])
+def test_odd_grids_and_rank_counts(ctx, n, nranks):
+    """Boxes whose edges are not multiples of the aggregate size (the row-partitioned coarsening stops at once and the
+    whole hierarchy is replicated), rank counts that are not powers of two, a rank that owns mostly metal."""
+    shift = yee.default_shift([1, 1, 1])
+    kw = dict(nev=3, basis=30, tol=1e-10, shift=shift, lin_type="cg", lin_tol=1e-11, prec_type="amg", block_size=1)
+    solver = mx.Solver(ctx, mx.Sim(n, pec_shape=PILLBOX_SHAPE, **BOX), mx.SolverParams(**kw))
+    assert solver.solve() == 3
+    k1 = np.sort([solver.result(i)["k2"].real for i in range(3)])
+
+    def rank(c):
+        s = mx.Solver(c, mxd.BoxSim(n, c.rank, nranks, pec_shape=PILLBOX_SHAPE, **BOX), mx.SolverParams(**kw))
+        nconv = s.solve()
+        res = [s.result(i)["k2"].real for i in range(nconv)]
+        s.close()
+        return res
+
+    out = _run_ranks(nranks, rank)
+    assert all(o == out[0] for o in out) and len(out[0]) == 3
+    assert np.abs(np.sort(out[0]) - k1).max() / np.abs(k1).max() < 1e-8
