@@ -65,6 +65,11 @@ class MxDistMultigrid {
     if (mTail) mxh_mg_destroy(mTail);
   }
   mxg_mg* handle() const { return mMg; }
+  // Chebyshev smoothing on the row-partitioned levels and on the replicated ones (COLLECTIVE: all-reduced norms)
+  void setChebyshev(double ratio) {
+    MX_ABI(mxg_mg_set_chebyshev(mMg, ratio), "MxDistMultigrid::setChebyshev");
+    if (mTail) MX_ABI(mxg_mg_set_chebyshev(mxh_mg_handle(mTail), ratio), "MxDistMultigrid::setChebyshev (replicated levels)");
+  }
   int numLevels() const { return (int)mA.size(); }
   int numReplicatedLevels() const { return mTailLevels; }
   int64_t globalRows(int l) const { return (int64_t)mA[l]->getRangeMap()->getGlobalNumIndices(); }

@@ -315,7 +315,23 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     return rcp(new MxCrsMatrix<double>(m->getRangeMap(), m->getDomainMap(), c.rowptr, colg, val));
   }
 
-  void buildMultigrid(Scalar*) {
+  // "linear solver : amg : smoother" (src/MxProblem.cpp:56): ML's default Chebyshev -> `sweeps` steps of the Chebyshev
+  // iteration for D^-1 A on [lmax / 7, lmax] per level (the ratio is tuned for these plain-aggregation hierarchies,
+  // profiles/r01g/multigrid_smoother_sweep.txt); "Jacobi" keeps damped Jacobi; others fall back to Chebyshev
+  void buildMultigrid(Scalar* tag) {
+    buildHierarchies(tag);
+    const std::string smoother = mPList.get("linear solver : amg : smoother", "Chebyshev");
+    if (smoother == "Jacobi" || smoother == "jacobi") return;
+    if (smoother != "Chebyshev" && pid == 0 && verbose)
+      std::cout << "MxMagWaveOp: amg smoother '" << smoother << "' -> Chebyshev (GPU, SpMV-only)\n";
+    const double ratio = 7.0;
+    if (mVecDmg) mVecDmg->setChebyshev(ratio);
+    if (mScaDmg) mScaDmg->setChebyshev(ratio);
+    if (mVecMg) MX_ABI(mxg_mg_set_chebyshev(mxh_mg_handle(mVecMg), ratio), "MxMagWaveOp (Chebyshev smoother)");
+    if (mScaMg) MX_ABI(mxg_mg_set_chebyshev(mxh_mg_handle(mScaMg), ratio), "MxMagWaveOp (Chebyshev smoother)");
+  }
+
+  void buildHierarchies(Scalar*) {
     const int sweeps = mPList.get("linear solver : amg : sweeps", 2);
     const int levels = mPList.get("linear solver : amg : max levels", 10);
     const mx::YeeAssembler<Scalar>& a = mSim->assemblerFor((Scalar*)0);

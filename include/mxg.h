@@ -184,6 +184,10 @@ int mxg_mg_create(mxg_ctx* ctx, int nlevels, mxg_csr* const* A, mxg_csr* const* 
                   int pre_sweeps, int post_sweeps, int coarse_sweeps, double omega, double coarse_scale,
                   mxg_mg** out);
 int mxg_mg_destroy(mxg_mg* mg);
+/* Chebyshev instead of damped-Jacobi smoothing on every level but the coarsest (ML's default smoother,
+ * src/MxProblem.cpp:56 "smoother" = "Chebyshev"): `sweeps` steps of the Chebyshev iteration for D^-1 A on
+ * [lmax / ratio, lmax], lmax estimated per level by power iteration here (ML's `smoother: Chebyshev alpha`). */
+int mxg_mg_set_chebyshev(mxg_mg* mg, double ratio);
 /* z = M^-1 r (one column), one V-cycle */
 int mxg_mg_apply(mxg_ctx* ctx, mxg_mg* mg, const mxg_mv* r, mxg_mv* z);
 /* Decomposed grid: below the last row-partitioned level the hierarchy continues REPLICATED on every rank.

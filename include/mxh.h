@@ -127,9 +127,11 @@ typedef struct mxh_solver_params {
   const char* lin_type;  /* "linear solver : type": "gmres" | "cg"  (default gmres) */
   int lin_basis;         /* "linear solver : basis"        (default 40) */
   double lin_tol;        /* "linear solver : tol"          (default 1e-6) */
-  const char* prec_type; /* "linear solver : prec type": "none" | "jacobi" (ilu/amg map to jacobi) */
+  const char* prec_type; /* "linear solver : prec type": "none" | "jacobi" | "ilu" (-> Jacobi) | "amg" (multigrid V-cycle) */
   int verbose;
   uint64_t seed;
+  const char* amg_smoother; /* "linear solver : amg : smoother": "Chebyshev" (default, src/MxProblem.cpp:56) | "Jacobi" */
+  int amg_sweeps;           /* "linear solver : amg : sweeps" (default 2) */
 } mxh_solver_params;
 
 void mxh_solver_default_params(mxh_solver_params* p);

@@ -35,7 +35,8 @@ class SolverParamsC(C.Structure):
     _fields_ = [("nev", C.c_int), ("basis", C.c_int), ("block_size", C.c_int),
                 ("max_restarts", C.c_int), ("tol", C.c_double), ("shift", C.c_double),
                 ("lin_type", C.c_char_p), ("lin_basis", C.c_int), ("lin_tol", C.c_double),
-                ("prec_type", C.c_char_p), ("verbose", C.c_int), ("seed", C.c_uint64)]
+                ("prec_type", C.c_char_p), ("verbose", C.c_int), ("seed", C.c_uint64),
+                ("amg_smoother", C.c_char_p), ("amg_sweeps", C.c_int)]
 
 
 # name -> (restype, argtypes); the list doubles as the export check of the CPU test-suite
@@ -92,6 +93,7 @@ MXG_SIGNATURES = {
     "mxg_mg_destroy": (C.c_int, [vp]),
     "mxg_mg_apply": (C.c_int, [vp, vp, vp, vp]),
     "mxg_mg_set_tail": (C.c_int, [vp, vp, c_i64p]),
+    "mxg_mg_set_chebyshev": (C.c_int, [vp, C.c_double]),
     "mxg_solve_cg": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "mxg_solve_gmres": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
 }

@@ -418,7 +418,9 @@ class Multigrid:
     ("scaLapl") of a Sim: hierarchy built on the host, V-cycle on the GPU."""
 
     def __init__(self, ctx, sim, op="shifted", shift=0.0, min_coarse=2000, max_levels=10, sweeps=2,
-                 coarse_sweeps=30, omega=0.85, coarse_scale=1.9):
+                 coarse_sweeps=30, omega=0.85, coarse_scale=1.9, smoother="jacobi", cheb_ratio=7.0):
+        """smoother: "jacobi" (damping omega) or "chebyshev" (ML's default; `sweeps` Chebyshev steps for D^-1 A on
+        [lmax / cheb_ratio, lmax], lmax per level by power iteration)."""
         self.lib = _lib.load_mxhost()
         self.ctx, self.sim = ctx, sim
         h = C.c_void_p()
@@ -427,6 +429,8 @@ class Multigrid:
                                     C.byref(h)), self.lib, "mxh")
         self.h = h
         self.handle = C.c_void_p(self.lib.mxh_mg_handle(h))
+        if smoother.lower() == "chebyshev":
+            _chk(ctx.lib.mxg_mg_set_chebyshev(self.handle, float(cheb_ratio)), ctx.lib)
         rows, nnz, nl = (C.c_int64 * 16)(), (C.c_int64 * 16)(), C.c_int()
         self.lib.mxh_mg_level_sizes(h, rows, nnz, C.byref(nl))
         self.levels = [(rows[i], nnz[i]) for i in range(nl.value)]
@@ -470,7 +474,7 @@ class SolverParams:
             self.set(k, v)
 
     def set(self, k, v):
-        if k in ("lin_type", "prec_type"):
+        if k in ("lin_type", "prec_type", "amg_smoother"):
             b = v.encode()
             self._keep.append(b)
             setattr(self.c, k, b)

@@ -614,14 +614,19 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 //      1  y = x + omega (rhs - A x) / diag   (one damped-Jacobi sweep; rows with diag == 0 keep x)
 //      2  y = rhs - A x                      (residual)
 //      3  y = y + omega A x                  (coarse-grid correction in place: A = prolongation)
+//      4  y = x + beta (x - y) + omega (rhs - A x) / diag   (Chebyshev smoother step, previous iterate in y)
 // (multigrid smoother / residual fused into the product: no separate pass over the vectors)
 template <int EPI>
 __device__ inline double cs_epilogue(double ax, long long row, const double* __restrict__ x,
                                      const double* __restrict__ rhs, const double* __restrict__ diag, double omega,
-                                     const double* y) {
+                                     double beta, const double* y) {
   if (EPI == 1) {
     const double dg = diag[row], xr = x[row];
     return dg != 0.0 ? xr + omega * (rhs[row] - ax) / dg : xr;
+  }
+  if (EPI == 4) {   // Chebyshev step, the previous iterate sits in y: y = x + beta (x - y) + omega (rhs - A x) / diag
+    const double dg = diag[row], xr = x[row];
+    return dg != 0.0 ? xr + beta * (xr - y[row]) + omega * (rhs[row] - ax) / dg : xr;
   }
   if (EPI == 2) return rhs[row] - ax;
   if (EPI == 3) return y[row] + omega * ax;
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     const double* __restrict__ x, double* __restrict__ y,
     const double* __restrict__ xdot, double* __restrict__ partial,
     const double* __restrict__ rhs, const double* __restrict__ diag, double omega,
-    const double* __restrict__ xg, long long nowned) {
+    const double* __restrict__ xg, long long nowned, double beta) {
   auto xat = [&](int cc) -> double { return (HALO && cc >= nowned) ? xg[cc - nowned] : x[cc]; };
   constexpr int RPT = CS_RPT, SB = CFG::SBLK / RPT;
   __shared__ __attribute__((aligned(16))) unsigned short scode[CFG::NNZ_BLK];
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
       double tr = 0.0;
 #pragma unroll 4
       for (int q = 0; q < SB; ++q) tr += svtab[q];   // (full unrolling of this cold loop would cost 256 VGPRs)
-      y[d.r0] = cs_epilogue<EPI>(tr, d.r0, x, rhs, diag, omega, y);
+      y[d.r0] = cs_epilogue<EPI>(tr, d.r0, x, rhs, diag, omega, beta, y);
       if (DOT) partial[b] = tr * xdot[d.r0];
     }
     return;
@@ -738,7 +743,7 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
   for (int r = 0; r < RPT; ++r) {
     const int row = t + r * SB;
     if (row < d.nr()) {
-      __builtin_nontemporal_store(cs_epilogue<EPI>(sum[r], d.r0 + row, x, rhs, diag, omega, y), y + d.r0 + row);
+      __builtin_nontemporal_store(cs_epilogue<EPI>(sum[r], d.r0 + row, x, rhs, diag, omega, beta, y), y + d.r0 + row);
       if (DOT) part += sum[r] * xdot[d.r0 + row];
     }
   }
@@ -1420,21 +1425,21 @@ static int launch_rowgather_halo(mxg_ctx* c, mxg_csr* a, const MvDesc& X, const 
 // boundary blocks with ghost reads.  halo_start(c, a, x) must have been called.
 template <bool DOT, int EPI>
 static int launch_cs_halo(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const double* xdot, double* partial,
-                          const double* rhs, const double* diag, double omega) {
+                          const double* rhs, const double* diag, double omega, double beta = 0.0) {
   const CsDesc* desc = (const CsDesc*)a->d_csdesc;
   const long long ni = a->ncs_interior, nb = a->ncs - a->ncs_interior;
   if (ni > 0) {
     const unsigned grid = (unsigned)(((ni + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
     hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, DOT, EPI, false>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream, desc, ni,
                        (const unsigned char*)a->d_csstream, (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, x, y,
-                       xdot, partial, rhs, diag, omega, (const double*)nullptr, 0LL);
+                       xdot, partial, rhs, diag, omega, (const double*)nullptr, 0LL, beta);
   }
   MXG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
   if (nb > 0) {
     const unsigned grid = (unsigned)(((nb + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
     hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, DOT, EPI, true>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream, desc + ni, nb,
                        (const unsigned char*)a->d_csstream, (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, x, y,
-                       xdot, DOT ? partial + ni : partial, rhs, diag, omega, (const double*)a->d_ghost, (long long)a->ncols_owned);
+                       xdot, DOT ? partial + ni : partial, rhs, diag, omega, (const double*)a->d_ghost, (long long)a->ncols_owned, beta);
   }
   MXG_HIP(hipGetLastError());
   return 0;
@@ -1499,7 +1504,7 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
                          (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
                          (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(j), Y.col(j),
                          (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0,
-                         (const double*)nullptr, 0LL);
+                         (const double*)nullptr, 0LL, 0.0);
   } else if ((a->kernel & 0x30000) && !a->is_complex && a->npipe > 0) {
     const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
@@ -1574,13 +1579,14 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
 // Product with a fused epilogue on a compressed matrix (single column, no halo): see cs_epilogue.
 // Returns 1 without touching y when the matrix is not compressed (the caller takes the unfused path).
 int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
-                          const double* diag, double omega) {
+                          const double* diag, double omega, double beta) {
   if (cs_halo_ok(a, x, y) && epi != 3) {
     if (halo_start(c, a, x) != 0) return 2;
     if (a->nrows == 0) { hipStreamWaitEvent(c->stream, c->ev_halo, 0); return 0; }
     (void)hipGetLastError();
     int rc;
     if (epi == 1) rc = launch_cs_halo<false, 1>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
+    else if (epi == 4) rc = launch_cs_halo<false, 4>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega, beta);
     else if (epi == 2) rc = launch_cs_halo<false, 2>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
     else rc = launch_cs_halo<false, 0>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
     return rc == 0 ? 0 : 2;
@@ -1596,8 +1602,9 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
   hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false, E>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,     \
                      (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,        \
                      (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0), \
-                     (const double*)nullptr, (double*)nullptr, rhs, diag, omega, (const double*)nullptr, 0LL)
-  if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else if (epi == 3) MXG_CS_EPI(3); else MXG_CS_EPI(0);
+                     (const double*)nullptr, (double*)nullptr, rhs, diag, omega, (const double*)nullptr, 0LL, beta)
+  if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else if (epi == 3) MXG_CS_EPI(3); else if (epi == 4) MXG_CS_EPI(4);
+  else MXG_CS_EPI(0);
 #undef MXG_CS_EPI
   if (hipGetLastError() != hipSuccess) { mxg_set_error("mxg_dev_csr_apply_epi: launch failed"); return 2; }
   return 0;
@@ -1633,7 +1640,7 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
                        (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
                        (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0),
                        (const double*)x->colptr(0), a->d_dotpartial, (const double*)nullptr, (const double*)nullptr, 0.0,
-                       (const double*)nullptr, 0LL);
+                       (const double*)nullptr, 0LL, 0.0);
   else
   hipLaunchKernelGGL((k_spmv_rowgather<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK), 0, c->stream,
                      (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr,

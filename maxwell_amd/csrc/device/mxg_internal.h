@@ -182,7 +182,7 @@ int mxg_dev_dot(mxg_ctx* ctx, const MvDesc& A, const MvDesc& B, double* d_out);
 // y = A x with the p.Ap of CG fused in (mxg_csr.hip); d_out is a device scalar
 // 0: launched; 1: matrix not compressed / shape not supported (nothing done); 2: launch error
 int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
-                          const double* diag, double omega);
+                          const double* diag, double omega, double beta = 0.0);
 int mxg_dev_csr_apply_dot(mxg_ctx* ctx, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out);
 
 inline int mxg_grid_for(int64_t n, int block, int per_thread, int cap) {

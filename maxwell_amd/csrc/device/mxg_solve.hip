@@ -161,6 +161,12 @@ struct mxg_mg {
   int pre = 2, post = 2, coarse = 20;
   double omega = 0.7, cscale = 1.9;
   // decomposed grid: replicated continuation below the last row-partitioned level (mxg_mg_set_tail)
+  // Chebyshev smoother (the reference's ML default, `smoother = Chebyshev`): per level the largest eigenvalue of
+  // D^-1 A (power iteration at setup); interval [lmax / ratio, boost * lmax]
+  bool cheb = false;
+  double cheb_ratio = 20.0;
+  std::vector<double> lmax;
+  std::vector<mxg_mv*> u;             // product scratch of the unfused Chebyshev step
   mxg_mg* tail = nullptr;
   std::vector<int64_t> tail_counts;
   int64_t tail_pad = 0, tail_off = 0;
@@ -199,11 +205,57 @@ __global__ void k_axpy1(long long n, double s, const double* __restrict__ t, dou
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) z[i] += s * t[i];
 }
 
+// t = z + beta (z - t) + omega D^-1 (r - u), u = A z   (unfused Chebyshev step; t holds the previous iterate)
+__global__ void k_cheb_step(long long n, const double* __restrict__ diag, double omega, double beta,
+                            const double* __restrict__ r, const double* __restrict__ u, const double* __restrict__ z,
+                            double* __restrict__ t) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double d = diag[i], zi = z[i];
+    t[i] = d != 0.0 ? zi + beta * (zi - t[i]) + omega * (r[i] - u[i]) / d : zi;
+  }
+}
+
+// `sweeps` steps of the Chebyshev iteration for D^-1 A on [lmax / ratio, lmax] (Saad, Iterative Methods, Alg. 12.1)
+int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
+  mxg_ctx* c = mg->ctx;
+  mxg_csr* A = mg->A[l];
+  const long long n = A->nrows;
+  const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
+  const double lmax = mg->lmax[l], lmin = lmax / mg->cheb_ratio;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma1 = theta / delta;
+  double rho = 1.0 / sigma1;
+  for (int s = 0; s < sweeps; ++s) {
+    double omega, beta;
+    if (s == 0) { omega = 1.0 / theta; beta = 0.0; }
+    else { const double rn = 1.0 / (2.0 * sigma1 - rho); omega = 2.0 * rn / delta; beta = rn * rho; rho = rn; }
+    if (s == 0 && zero_guess) {
+      hipLaunchKernelGGL(k_jac_first, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag, omega,
+                         (const double*)mg->r[l]->colptr(0), mg->z[l]->colptr(0));
+      MXG_HIP(hipMemsetAsync(mg->t[l]->colptr(0), 0, sizeof(double) * n, c->stream));   // previous iterate: 0
+      continue;
+    }
+    // the previous iterate sits in t and is overwritten by the new one
+    const int rc = mxg_dev_csr_apply_epi(c, A, mg->z[l], mg->t[l], s == 0 ? 1 : 4, mg->r[l]->colptr(0), A->d_diag, omega, beta);
+    if (rc > 1) return 1;
+    if (rc == 1) {
+      MXG_TRY(mxg_csr_apply(c, A, mg->z[l], mg->u[l]));
+      hipLaunchKernelGGL(k_cheb_step, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag, omega,
+                         s == 0 ? 0.0 : beta, (const double*)mg->r[l]->colptr(0), (const double*)mg->u[l]->colptr(0),
+                         (const double*)mg->z[l]->colptr(0), mg->t[l]->colptr(0));
+    }
+    std::swap(mg->z[l], mg->t[l]);
+  }
+  MXG_HIP(hipGetLastError());
+  return 0;
+}
+
 int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
   mxg_ctx* c = mg->ctx;
   mxg_csr* A = mg->A[l];
   const long long n = A->nrows;
   const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
+  if (mg->cheb && l < mg->nlevels - 1) return mg_smooth_cheb(mg, l, sweeps, zero_guess);
   for (int s = 0; s < sweeps; ++s) {
     if (s == 0 && zero_guess) {
       hipLaunchKernelGGL(k_jac_first, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag,
@@ -303,7 +355,50 @@ extern "C" int mxg_mg_create(mxg_ctx* c, int nlevels, mxg_csr* const* A, mxg_csr
     MXG_TRY(mxg_mv_create(c, A[l]->nrows, 1, 0, &t));
     mg->r.push_back(r); mg->z.push_back(z); mg->t.push_back(t);
   }
+  if (const char* e = getenv("MXG_MG_CSCALE")) mg->cscale = atof(e);       // experiments (scripts/mg_smoother_sweep.py)
+
   *out = mg;
+  return 0;
+}
+
+// Chebyshev smoothing on every level but the coarsest: lmax(D^-1 A) by power iteration (all-reduced norms on a
+// decomposed grid), interval [boost * lmax / ratio, boost * lmax]
+extern "C" int mxg_mg_set_chebyshev(mxg_mg* mg, double ratio) {
+  MXG_CHECK(mg && ratio > 1.0, "mxg_mg_set_chebyshev: bad argument");
+  mxg_ctx* c = mg->ctx;
+  double boost = 1.1;
+  if (const char* e = getenv("MXG_MG_CHEB_BOOST")) boost = atof(e);
+  if (const char* e = getenv("MXG_MG_CHEB_RATIO")) ratio = atof(e);        // experiments (scripts/mg_smoother_sweep.py)
+  mg->cheb_ratio = ratio;
+  mg->lmax.assign(mg->nlevels, 2.0);
+  for (int l = 0; l < mg->nlevels; ++l) {
+    if ((int)mg->u.size() <= l) {
+      mxg_mv* u;
+      MXG_TRY(mxg_mv_create(c, mg->A[l]->nrows, 1, 0, &u));
+      mg->u.push_back(u);
+    }
+    if (l == mg->nlevels - 1 && mg->nlevels > 1) continue;
+    mxg_csr* A = mg->A[l];
+    const long long n = A->nrows;
+    const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
+    mxg_mv *v = mg->z[l], *w = mg->t[l];
+    MXG_TRY(mxg_mv_random(v, 777 + l));
+    double lam = 1.0, nv = 0.0, nw = 0.0;
+    for (int it = 0; it < 15; ++it) {
+      MXG_TRY(mxg_mv_norm2(v, &nv));
+      if (!(nv > 0.0)) break;
+      MXG_TRY(mxg_mv_scale(v, 1.0 / nv, 0.0));
+      MXG_TRY(mxg_csr_apply(c, A, v, mg->u[l]));
+      hipLaunchKernelGGL(k_jac_first, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag, 1.0,
+                         (const double*)mg->u[l]->colptr(0), w->colptr(0));      // w = D^-1 A v (0 on inactive rows)
+      MXG_HIP(hipGetLastError());
+      MXG_TRY(mxg_mv_norm2(w, &nw));
+      lam = nw;
+      std::swap(v, w);
+    }
+    mg->lmax[l] = boost * lam;
+  }
+  mg->cheb = true;
   return 0;
 }
 
@@ -337,6 +432,7 @@ extern "C" int mxg_mg_destroy(mxg_mg* mg) {
   for (auto* v : mg->r) mxg_mv_destroy(v);
   for (auto* v : mg->z) mxg_mv_destroy(v);
   for (auto* v : mg->t) mxg_mv_destroy(v);
+  for (auto* v : mg->u) mxg_mv_destroy(v);
   delete mg;
   return 0;
 }

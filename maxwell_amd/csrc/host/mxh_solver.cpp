@@ -12,6 +12,7 @@ extern "C" void mxh_solver_default_params(mxh_solver_params* p) {
   p->nev = 10; p->basis = 20; p->block_size = 1; p->max_restarts = 100; p->tol = 1.0e-6; p->shift = 0.0;
   p->lin_type = "gmres"; p->lin_basis = 40; p->lin_tol = 1.0e-6; p->prec_type = "none";
   p->verbose = 0; p->seed = 12345;
+  p->amg_smoother = "Chebyshev"; p->amg_sweeps = 2;      // src/MxProblem.cpp:56-57
 }
 
 void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::ParameterList const& pl) {
@@ -62,6 +63,9 @@ extern "C" int mxh_solver_create(mxg_ctx* ctx, mxh_sim* sim, const mxh_solver_pa
     pl.set("linear solver : basis", p->lin_basis);
     pl.set("linear solver : tol", p->lin_tol);
     pl.set("linear solver : prec type", s->precType.c_str());
+    s->amgSmoother = p->amg_smoother ? p->amg_smoother : "Chebyshev";
+    pl.set("linear solver : amg : smoother", s->amgSmoother.c_str());
+    pl.set("linear solver : amg : sweeps", p->amg_sweeps > 0 ? p->amg_sweeps : 2);
     mxh_solver_build(*s, ctx, sim, pl);
     *out = s.release();
     return 0;

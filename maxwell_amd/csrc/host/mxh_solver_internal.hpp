@@ -18,7 +18,7 @@ struct mxh_solver {
   std::unique_ptr<MxSolver<3, double> > solver;            // real problems
   std::unique_ptr<MxSolver<3, MxComplex> > csolver;        // complex problems (Bloch phase shifts)
   mxh_solver_params params;
-  std::string linType, precType;
+  std::string linType, precType, amgSmoother;
 };
 
 // comm + MxEMSim (sharing the assembler of `sim`) + MxSolver from a complete parameter list

@@ -79,13 +79,15 @@ def test_unconverged_is_reported_not_spun(ctx, oracle_pillbox12, rng):
     assert not conv and iters <= 6 and res > 1e-14
 
 
-def test_multigrid_preconditioner(ctx, rng):
+@pytest.mark.parametrize("smoother", ["jacobi", "chebyshev"])
+def test_multigrid_preconditioner(ctx, rng, smoother):
     """K11 replacement: the aggregation V-cycle is a fixed symmetric operator (legal for CG), cuts the
-    iteration count by an order of magnitude, and the solution is the same."""
+    iteration count by an order of magnitude, and the solution is the same.  Smoothers: damped Jacobi and ML's
+    default Chebyshev (polynomial in D^-1 A: the cycle stays symmetric)."""
     sim = mx.Sim.pillbox(32)
     shift = yee.default_shift([1, 1, 1])
     for op in ("shifted", "scaLapl"):
-        mg = mx.Multigrid(ctx, sim, op, shift, min_coarse=500)
+        mg = mx.Multigrid(ctx, sim, op, shift, min_coarse=500, smoother=smoother)
         assert len(mg.levels) >= 3 and mg.levels[-1][0] < mg.levels[0][0] // 30
         A = mg.fine_matrix()
         n = A.nrows
