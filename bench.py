@@ -270,7 +270,7 @@ def eigen_bench(mx, ctx, n):
         % (n, t1 - t0, t2 - t1, time.perf_counter() - t2))
     st = solver.stats()
     res = [solver.result(i) for i in range(nconv)]
-    return {"workload": "pillbox %d^3, nev 5, tol 1e-8, block Krylov-Schur shift-invert, multigrid-preconditioned CG inner solves (tol 1e-9)" % n,
+    return {"workload": "pillbox %d^3, nev 5, tol 1e-8, block Krylov-Schur shift-invert, multigrid-preconditioned CG inner solves (tol 1e-9; V(2,2), Chebyshev smoother)" % n,
             "assembly_seconds": round(t1 - t0, 2), "solver_setup_seconds": round(t2 - t1, 2),
             "eigenpairs_per_s": round(nconv / st["eigensolve_seconds"], 4), "converged": nconv,
             "eigensolve_seconds": round(st["eigensolve_seconds"], 3), "applies": st["applies"],

@@ -165,6 +165,8 @@ struct mxg_mg {
   // D^-1 A (power iteration at setup); interval [lmax / ratio, boost * lmax]
   bool cheb = false;
   double cheb_ratio = 20.0;
+  int coarse_cheb_degree = 0;         // coarsest level: Chebyshev of this degree instead of `coarse` Jacobi sweeps (0 = Jacobi)
+  double coarse_cheb_ratio = 100.0;
   std::vector<double> lmax;
   std::vector<mxg_mv*> u;             // product scratch of the unfused Chebyshev step
   mxg_mg* tail = nullptr;
@@ -217,12 +219,12 @@ __global__ void k_cheb_step(long long n, const double* __restrict__ diag, double
 }
 
 // `sweeps` steps of the Chebyshev iteration for D^-1 A on [lmax / ratio, lmax] (Saad, Iterative Methods, Alg. 12.1)
-int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
+int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio) {
   mxg_ctx* c = mg->ctx;
   mxg_csr* A = mg->A[l];
   const long long n = A->nrows;
   const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
-  const double lmax = mg->lmax[l], lmin = lmax / mg->cheb_ratio;
+  const double lmax = mg->lmax[l], lmin = lmax / ratio;
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma1 = theta / delta;
   double rho = 1.0 / sigma1;
   for (int s = 0; s < sweeps; ++s) {
@@ -255,7 +257,8 @@ int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
   mxg_csr* A = mg->A[l];
   const long long n = A->nrows;
   const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
-  if (mg->cheb && l < mg->nlevels - 1) return mg_smooth_cheb(mg, l, sweeps, zero_guess);
+  if (mg->cheb && l < mg->nlevels - 1) return mg_smooth_cheb(mg, l, sweeps, zero_guess, mg->cheb_ratio);
+  if (mg->cheb && mg->coarse_cheb_degree > 0) return mg_smooth_cheb(mg, l, mg->coarse_cheb_degree, zero_guess, mg->coarse_cheb_ratio);
   for (int s = 0; s < sweeps; ++s) {
     if (s == 0 && zero_guess) {
       hipLaunchKernelGGL(k_jac_first, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag,
@@ -377,7 +380,6 @@ extern "C" int mxg_mg_set_chebyshev(mxg_mg* mg, double ratio) {
       MXG_TRY(mxg_mv_create(c, mg->A[l]->nrows, 1, 0, &u));
       mg->u.push_back(u);
     }
-    if (l == mg->nlevels - 1 && mg->nlevels > 1) continue;
     mxg_csr* A = mg->A[l];
     const long long n = A->nrows;
     const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
@@ -397,6 +399,14 @@ extern "C" int mxg_mg_set_chebyshev(mxg_mg* mg, double ratio) {
       std::swap(v, w);
     }
     mg->lmax[l] = boost * lam;
+  }
+  // coarsest level ("coarse smoother" = Chebyshev, src/MxProblem.cpp:58): degree 16 on [lmax / 50, lmax] solves the
+  // <= 2000-row problem as well as any longer iteration and takes half the launches of 30 Jacobi sweeps
+  mg->coarse_cheb_degree = 16;
+  mg->coarse_cheb_ratio = 50.0;
+  if (const char* e = getenv("MXG_MG_COARSE_CHEB")) {                       // experiments: "degree:ratio", 0 = Jacobi sweeps
+    mg->coarse_cheb_degree = atoi(e);
+    if (const char* q = strchr(e, ':')) mg->coarse_cheb_ratio = atof(q + 1);
   }
   mg->cheb = true;
   return 0;

@@ -33,20 +33,25 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--ratios", default="8,14,20,30")
     ap.add_argument("--cscales", default="1.0,1.5,1.9")
+    ap.add_argument("--coarse", default="", help="coarsest-level Chebyshev variants, e.g. 10:30,10:100 (degree:ratio)")
     a = ap.parse_args()
     variants = [("jacobi", None, None)]
     for ratio in [float(v) for v in a.ratios.split(",")]:
         for cs in [float(v) for v in a.cscales.split(",")]:
             variants.append(("cheb", ratio, cs))
+    variants = [v + (None,) for v in variants]
+    for cc in [c for c in a.coarse.split(",") if c]:
+        variants.append(("cheb", float(a.ratios.split(",")[0]), float(a.cscales.split(",")[-1]), cc))
     rows = []
-    for sm, ratio, cs in variants:
+    for sm, ratio, cs, cc in variants:
         env = dict(os.environ)
+        if cc: env["MXG_MG_COARSE_CHEB"] = cc
         if ratio: env["MXG_MG_CHEB_RATIO"] = str(ratio)
         if cs: env["MXG_MG_CSCALE"] = str(cs)
         r = subprocess.run([sys.executable, "-c", WORKER, str(a.cells), "Jacobi" if sm == "jacobi" else "Chebyshev"], capture_output=True, text=True, env=env, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         res = json.loads(line[0][7:]) if line else {"error": r.stderr[-300:]}
-        res.update(smoother=sm, ratio=ratio, cscale=cs)
+        res.update(smoother=sm, ratio=ratio, cscale=cs, coarse=cc)
         rows.append(res)
         print(json.dumps(res), flush=True)
     if a.out:
