@@ -15,10 +15,10 @@ import json, sys, time
 import numpy as np
 sys.path.insert(0, %r)
 import maxwell_amd as mx
-n = int(sys.argv[1]); smoother = sys.argv[2]
+n = int(sys.argv[1]); smoother = sys.argv[2]; sweeps = int(sys.argv[3])
 ctx = mx.Ctx(0)
 sim = mx.Sim.pillbox(n)
-p = mx.SolverParams(nev=5, basis=30, tol=1e-8, shift=0.05 * (2.0 * np.pi) ** 2, lin_type="cg", lin_tol=1e-9, prec_type="amg", amg_smoother=smoother)
+p = mx.SolverParams(nev=5, basis=30, tol=1e-8, shift=0.05 * (2.0 * np.pi) ** 2, lin_type="cg", lin_tol=1e-9, prec_type="amg", amg_smoother=smoother, amg_sweeps=sweeps)
 s = mx.Solver(ctx, sim, p)
 nconv = s.solve()
 st = s.stats()
@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--ratios", default="8,14,20,30")
     ap.add_argument("--cscales", default="1.0,1.5,1.9")
+    ap.add_argument("--sweeps", type=int, default=2, help="smoother steps per level (the deck's `sweeps`)")
     ap.add_argument("--coarse", default="", help="coarsest-level Chebyshev variants, e.g. 10:30,10:100 (degree:ratio)")
     a = ap.parse_args()
     variants = [("jacobi", None, None)]
@@ -48,10 +49,10 @@ def main():
         if cc: env["MXG_MG_COARSE_CHEB"] = cc
         if ratio: env["MXG_MG_CHEB_RATIO"] = str(ratio)
         if cs: env["MXG_MG_CSCALE"] = str(cs)
-        r = subprocess.run([sys.executable, "-c", WORKER, str(a.cells), "Jacobi" if sm == "jacobi" else "Chebyshev"], capture_output=True, text=True, env=env, timeout=900)
+        r = subprocess.run([sys.executable, "-c", WORKER, str(a.cells), "Jacobi" if sm == "jacobi" else "Chebyshev", str(a.sweeps)], capture_output=True, text=True, env=env, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         res = json.loads(line[0][7:]) if line else {"error": r.stderr[-300:]}
-        res.update(smoother=sm, ratio=ratio, cscale=cs, coarse=cc)
+        res.update(smoother=sm, ratio=ratio, cscale=cs, coarse=cc, sweeps=a.sweeps)
         rows.append(res)
         print(json.dumps(res), flush=True)
     if a.out:
