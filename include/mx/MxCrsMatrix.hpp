@@ -201,7 +201,7 @@ class MxCrsMatrix {
     // MXG_COMPRESS=0 keeps the plain CSR kernels.  With ghost columns the blocks that reference none are ordered
     // first and overlap the halo exchange, exactly as with the CSR kernel.
     static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
-    if (compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 4096)
+    if (compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 256)
       MX_ABI(mxg_csr_compress_from(mDev, mHost.rowptr.data(), mHost.col.data(),
                                    reinterpret_cast<const double*>(mHost.val.data()), NULL, NULL, NULL),
              "MxCrsMatrix::fillComplete (compress)");

@@ -615,6 +615,7 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 //      2  y = rhs - A x                      (residual)
 //      3  y = y + omega A x                  (coarse-grid correction in place: A = prolongation)
 //      4  y = x + beta (x - y) + omega (rhs - A x) / diag   (Chebyshev smoother step, previous iterate in y)
+//      5  y = (1 + beta) x + omega (rhs - A x) / diag       (the same after a zero previous iterate)
 // (multigrid smoother / residual fused into the product: no separate pass over the vectors)
 template <int EPI>
 __device__ inline double cs_epilogue(double ax, long long row, const double* __restrict__ x,
@@ -623,6 +624,10 @@ __device__ inline double cs_epilogue(double ax, long long row, const double* __r
   if (EPI == 1) {
     const double dg = diag[row], xr = x[row];
     return dg != 0.0 ? xr + omega * (rhs[row] - ax) / dg : xr;
+  }
+  if (EPI == 5) {   // Chebyshev step after a zero previous iterate: y = (1 + beta) x + omega (rhs - A x) / diag
+    const double dg = diag[row], xr = x[row];
+    return dg != 0.0 ? xr + beta * xr + omega * (rhs[row] - ax) / dg : xr;
   }
   if (EPI == 4) {   // Chebyshev step, the previous iterate sits in y: y = x + beta (x - y) + omega (rhs - A x) / diag
     const double dg = diag[row], xr = x[row];
@@ -1587,6 +1592,7 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
     int rc;
     if (epi == 1) rc = launch_cs_halo<false, 1>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
     else if (epi == 4) rc = launch_cs_halo<false, 4>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 5) rc = launch_cs_halo<false, 5>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega, beta);
     else if (epi == 2) rc = launch_cs_halo<false, 2>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
     else rc = launch_cs_halo<false, 0>(c, a, x->colptr(0), y->colptr(0), nullptr, nullptr, rhs, diag, omega);
     return rc == 0 ? 0 : 2;
@@ -1604,7 +1610,7 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
                      (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0), \
                      (const double*)nullptr, (double*)nullptr, rhs, diag, omega, (const double*)nullptr, 0LL, beta)
   if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else if (epi == 3) MXG_CS_EPI(3); else if (epi == 4) MXG_CS_EPI(4);
-  else MXG_CS_EPI(0);
+  else if (epi == 5) MXG_CS_EPI(5); else MXG_CS_EPI(0);
 #undef MXG_CS_EPI
   if (hipGetLastError() != hipSuccess) { mxg_set_error("mxg_dev_csr_apply_epi: launch failed"); return 2; }
   return 0;

@@ -210,11 +210,11 @@ __global__ void k_axpy1(long long n, double s, const double* __restrict__ t, dou
 // t = z + beta (z - t) + omega D^-1 (r - u), u = A z   (unfused Chebyshev step; t holds the previous iterate)
 __global__ void k_cheb_step(long long n, const double* __restrict__ diag, double omega, double beta,
                             const double* __restrict__ r, const double* __restrict__ u, const double* __restrict__ z,
-                            double* __restrict__ t) {
+                            double* __restrict__ t, int prev_zero) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double d = diag[i], zi = z[i];
-    t[i] = d != 0.0 ? zi + beta * (zi - t[i]) + omega * (r[i] - u[i]) / d : zi;
+    const double d = diag[i], zi = z[i], prev = prev_zero ? 0.0 : t[i];
+    t[i] = d != 0.0 ? zi + beta * (zi - prev) + omega * (r[i] - u[i]) / d : zi;
   }
 }
 
@@ -227,6 +227,7 @@ int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio)
   const double lmax = mg->lmax[l], lmin = lmax / ratio;
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma1 = theta / delta;
   double rho = 1.0 / sigma1;
+  bool prev_zero = false;             // the previous iterate is the zero guess: nothing to read
   for (int s = 0; s < sweeps; ++s) {
     double omega, beta;
     if (s == 0) { omega = 1.0 / theta; beta = 0.0; }
@@ -234,18 +235,20 @@ int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio)
     if (s == 0 && zero_guess) {
       hipLaunchKernelGGL(k_jac_first, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag, omega,
                          (const double*)mg->r[l]->colptr(0), mg->z[l]->colptr(0));
-      MXG_HIP(hipMemsetAsync(mg->t[l]->colptr(0), 0, sizeof(double) * n, c->stream));   // previous iterate: 0
+      prev_zero = true;
       continue;
     }
     // the previous iterate sits in t and is overwritten by the new one
-    const int rc = mxg_dev_csr_apply_epi(c, A, mg->z[l], mg->t[l], s == 0 ? 1 : 4, mg->r[l]->colptr(0), A->d_diag, omega, beta);
+    const int epi = s == 0 ? 1 : (prev_zero ? 5 : 4);
+    const int rc = mxg_dev_csr_apply_epi(c, A, mg->z[l], mg->t[l], epi, mg->r[l]->colptr(0), A->d_diag, omega, beta);
     if (rc > 1) return 1;
     if (rc == 1) {
       MXG_TRY(mxg_csr_apply(c, A, mg->z[l], mg->u[l]));
       hipLaunchKernelGGL(k_cheb_step, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag, omega,
                          s == 0 ? 0.0 : beta, (const double*)mg->r[l]->colptr(0), (const double*)mg->u[l]->colptr(0),
-                         (const double*)mg->z[l]->colptr(0), mg->t[l]->colptr(0));
+                         (const double*)mg->z[l]->colptr(0), mg->t[l]->colptr(0), (s == 0 || prev_zero) ? 1 : 0);
     }
+    prev_zero = false;
     std::swap(mg->z[l], mg->t[l]);
   }
   MXG_HIP(hipGetLastError());

@@ -24,7 +24,7 @@ static mxg_csr* upload(mxg_ctx* ctx, const mx::Csr<double>& m) {
   if (mxg_csr_create(ctx, m.nrows, m.ncols, 0, m.rowptr.data(), m.col.data(), m.val.data(), 0, nullptr, &d) != 0)
     throw std::runtime_error(std::string("mxg_csr_create: ") + mxg_last_error());
   static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
-  if (compress && m.nrows >= 4096 &&
+  if (compress && m.nrows >= 256 &&    // small levels too: their sweeps are launch-bound, the fused epilogues halve the launches
       mxg_csr_compress_from(d, m.rowptr.data(), m.col.data(), m.val.data(), nullptr, nullptr, nullptr) != 0)
     throw std::runtime_error(std::string("mxg_csr_compress: ") + mxg_last_error());
   return d;
