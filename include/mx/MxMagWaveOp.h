@@ -33,8 +33,16 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     shift = mPList.get("eigensolver : shift", 0.0);
     verbose = mPList.get("eigensolver : output", 1);
     if (pid == 0 && verbose) std::cout << "shift is: " << shift << "\n";
+    const bool timing = getenv("MXH_VERBOSE") != nullptr && pid == 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (timing) std::cerr << "[MxMagWaveOp] " << what << " " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s\n";
+      t0 = std::chrono::steady_clock::now();
+    };
     initMatrices();
+    lap("operator chain");
     setShift(Scalar(shift));
+    lap("shifted matrix, device copies, preconditioner");
     initWorkVecs();
   }
 
@@ -250,6 +258,13 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   }
 
   void setLinearSolvers() {   // :286-355
+    const bool timing = getenv("MXH_VERBOSE") != nullptr && pid == 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (timing) std::cerr << "[MxMagWaveOp]   " << what << " " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s\n";
+      t0 = std::chrono::steady_clock::now();
+    };
+    struct LapAtExit { decltype(lap)& f; ~LapAtExit() { f("preconditioner setup"); } };
     // device copies (upload + stream encoding) belong to setup, not to the first Apply
     mShiftedVecLapl->getRawMatrix();
     mRhs->getRawMatrix();
@@ -258,6 +273,8 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
       mEMOps->getOp("divB")->getRawMatrix();
       mEMOps->getOp("gradPsi")->getRawMatrix();
     }
+    lap("device copies + stream encoding of the Apply operators");
+    LapAtExit atExit{lap};
     std::string precType = mPList.get("linear solver : prec type", "none");
     if (precType == "gmg") {
       if (pid == 0) std::cout << "Using GMRES with geometric multigrid preconditioner.\nNot implemented.\n";
