@@ -33,9 +33,17 @@ class MxEMOps {
   }
   RCP<MxCrsMatrix<Scalar> > getOp(std::string name) const {
     auto it = mOps.find(name);
+    if (it == mOps.end() && mSource && mSource->count(name)) {
+      // first use of an operator of the prebuilt chain: adopt it now (on a decomposed grid this agrees its ghost
+      // import, a collective - every rank asks for the same operators in the same order)
+      const_cast<MxEMOps*>(this)->adopt(name, mSource->at(name));
+      it = mOps.find(name);
+    }
     if (it == mOps.end()) { std::cout << "MxEMOps::getOp: operator '" << name << "' not found.\n"; exit(EXIT_FAILURE); }
     return it->second;
   }
+  // operators assembled elsewhere (MxEMSim::prebuiltOps) that getOp adopts on first use
+  void setSource(const std::map<std::string, mx::Csr<Scalar> >* src) { mSource = src; }
   // product of the named operators, FIRST NAME APPLIED FIRST (src/MxEMOps.h:61-74):
   // result = names[n-1] * ... * names[1] * names[0]  (massiveCrsMultiply, src/MxUtil.cpp:318-371)
   RCP<MxCrsMatrix<Scalar> > multiplyOps(std::vector<std::string> const& names, std::vector<bool> const& transposes,
@@ -109,6 +117,7 @@ class MxEMOps {
   int pid;
   RCP<MxEMSim<DIM> > mSim;
   std::map<std::string, RCP<MxCrsMatrix<Scalar> > > mOps;
+  const std::map<std::string, mx::Csr<Scalar> >* mSource = nullptr;
 };
 
 #endif

@@ -239,8 +239,8 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     auto pre = mSim->prebuiltOps((Scalar*)0);
     if (!pre || !pre->count("vecLapl") || !pre->count("scaLapl") || !pre->count("mRhs")) return false;
     mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim, false));
-    for (auto const& e : *pre) mEMOps->adopt(e.first, e.second);
-    mVecLapl = mEMOps->getOp("vecLapl");
+    mEMOps->setSource(pre);                                       // adopted on first use: most of the chain's factors never are
+    if (!mSim->isDistributed()) mVecLapl = mEMOps->getOp("vecLapl");   // (a decomposed grid shifts on the window, setShift)
     mScaLapl = mEMOps->getOp("scaLapl");
     mRhs = mEMOps->getOp("mRhs");
     return true;
