@@ -6,7 +6,8 @@
 A step is one application of the shifted vector Laplacian (vecLapl - shift*dmA, the matrix
 every inner Krylov iteration of MxMagWaveOp::Apply multiplies with) to one block of vectors
 resident in HBM.  N = 1: example/pillbox.py geometry at 256^3 Yee cells (BASELINE.json configs[1]).
-N > 1: one GPU per MxGridDomain sub-box, weak scaling (every rank owns a 256^3-cell box).
+N > 1: one GPU per MxGridDomain sub-box, weak scaling (every rank owns a 256^3-cell box); the `eigen` object then
+holds the decomposed solve of the N = 1 eigen problem (256^3 over all ranks: strong scaling).
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (HIP-event timed, against
 the 8 TB/s HBM3E peak, algorithmic bytes of SURVEY 8d) and `cpu_baseline` (the oracle's plain-C
