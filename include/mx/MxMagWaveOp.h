@@ -297,8 +297,10 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
       exit(EXIT_FAILURE);
     }
     std::string invType = mPList.get("linear solver : type", "gmres");
+    mUseBicg = false;
     if (invType == "gmres") mUseCg = false;
     else if (invType == "cg") mUseCg = true;
+    else if (invType == "bicgstab") { mUseCg = false; mUseBicg = true; }   // AZ_bicgstab, src/MxMagWaveOp.cpp:333-334
     else { std::cout << "MxMagWaveOp: solver type '" << invType << "' not implemented.\n"; throw 1; }
     linBasis = mPList.get("linear solver : basis", 20);
     mOpts.tol = linTol;
@@ -388,6 +390,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mxg_solve_opts o = mOpts;
     o.mg = (mUseMg && mg) ? mg : nullptr;
     if (o.precond == 3 && !o.mg) o.precond = 1;
+    if (mUseBicg) return mxg_solve_bicgstab(ctx, A, b, x, &o, info);
     return mUseCg ? mxg_solve_cg(ctx, A, b, x, &o, info) : mxg_solve_gmres(ctx, A, b, x, &o, info);
   }
 
@@ -403,6 +406,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   int linBasis;
   int verbose;
   bool mUseCg = false;
+  bool mUseBicg = false;
   bool mUseMg = false;
   mxh_mg* mVecMg = nullptr;
   mxh_mg* mScaMg = nullptr;

@@ -219,6 +219,9 @@ int mxg_solve_cg(mxg_ctx* ctx, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
                  const mxg_solve_opts* opts, mxg_solve_info* info);
 int mxg_solve_gmres(mxg_ctx* ctx, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
                     const mxg_solve_opts* opts, mxg_solve_info* info);
+/* AZ_bicgstab (src/MxMagWaveOp.cpp:333-334): right-preconditioned BiCGStab, same stopping rule */
+int mxg_solve_bicgstab(mxg_ctx* ctx, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
+                    const mxg_solve_opts* opts, mxg_solve_info* info);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,7 @@ MXG_SIGNATURES = {
     "mxg_mg_set_chebyshev": (C.c_int, [vp, C.c_double]),
     "mxg_solve_cg": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
     "mxg_solve_gmres": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
+    "mxg_solve_bicgstab": (C.c_int, [vp, vp, vp, vp, C.POINTER(SolveOpts), C.POINTER(SolveInfo)]),
 }
 
 MXH_SIGNATURES = {

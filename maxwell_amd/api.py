@@ -303,7 +303,7 @@ class CsrMatrix:
         opts = _lib.SolveOpts(tol, restart, max_iters, {"none": 0, "jacobi": 1, "mg": 3}[precond], 0, 0.0, 0.0,
                               mg.handle if mg is not None else None)
         info = _lib.SolveInfo()
-        fn = self.lib.mxg_solve_cg if method == "cg" else self.lib.mxg_solve_gmres
+        fn = {"cg": self.lib.mxg_solve_cg, "gmres": self.lib.mxg_solve_gmres, "bicgstab": self.lib.mxg_solve_bicgstab}[method]
         _chk(fn(self.ctx.h, self.h, b.h, x.h, C.byref(opts), C.byref(info)), self.lib)
         return info.iters, bool(info.converged), info.true_res
 

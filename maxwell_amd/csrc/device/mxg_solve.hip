@@ -640,6 +640,83 @@ extern "C" int mxg_solve_cg(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_m
   return 0;
 }
 
+// AZ_bicgstab (src/MxMagWaveOp.cpp:333-334): right-preconditioned BiCGStab, short recurrences for the
+// non-symmetric operators (FIT inverse permittivity) - two products and two preconditioner applications per
+// iteration, no basis to orthogonalise against.  Stops on the unscaled true residual like the other solvers.
+extern "C" int mxg_solve_bicgstab(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
+                                  const mxg_solve_opts* o, mxg_solve_info* info) {
+  MXG_CHECK(c && A && b && x && o && info, "mxg_solve_bicgstab: NULL argument");
+  MXG_CHECK(A->nrows == A->ncols_owned, "mxg_solve_bicgstab: matrix must be square");
+  MXG_CHECK(b->k == x->k && b->nlocal == A->nrows && x->nlocal == A->nrows, "mxg_solve_bicgstab: shape mismatch");
+  const int cx = A->is_complex;
+  const int max_iters = o->max_iters > 0 ? o->max_iters : 100000;
+  info->iters = 0; info->converged = 1; info->true_res = 0.0;
+  Guard g;
+  mxg_mv *r, *rh, *p, *v, *y, *sv, *z, *t;
+  for (mxg_mv** w : {&r, &rh, &p, &v, &y, &sv, &z, &t}) MXG_TRY(g.make(c, A->nrows, 1, cx, w));
+  auto cdot = [&](const mxg_mv* a, const mxg_mv* bb, cplx* out) -> int {   // a^H b
+    double d[2] = {0.0, 0.0};
+    MXG_TRY(mxg_mv_dot(a, bb, d));
+    *out = cplx(d[0], cx ? d[1] : 0.0);
+    return 0;
+  };
+  for (int col = 0; col < b->k; ++col) {
+    mxg_mv *bj, *xj;
+    MXG_TRY(g.view(const_cast<mxg_mv*>(b), col, 1, &bj));
+    MXG_TRY(g.view(x, col, 1, &xj));
+    double res = 0.0;
+    MXG_TRY(true_residual(c, A, bj, xj, r, &res));
+    int it = 0;
+    while (res > o->tol && it < max_iters) {       // (re)start from the true residual
+      MXG_TRY(mxg_mv_copy(rh, r));
+      MXG_TRY(mxg_mv_fill(p, 0.0, 0.0));
+      MXG_TRY(mxg_mv_fill(v, 0.0, 0.0));
+      cplx rho = 1.0, alpha = 1.0, omega = 1.0;
+      double rnorm = res;
+      bool broke = false;
+      while (rnorm > o->tol && it < max_iters) {
+        cplx rho_new;
+        MXG_TRY(cdot(rh, r, &rho_new));
+        if (rho_new == cplx(0.0) || omega == cplx(0.0)) { broke = true; break; }
+        const cplx beta = (rho_new / rho) * (alpha / omega);
+        rho = rho_new;
+        // p = r + beta (p - omega v)
+        MXG_TRY(mxg_mv_axpby(-omega.real(), -omega.imag(), v, 1.0, 0.0, p));
+        MXG_TRY(mxg_mv_axpby(1.0, 0.0, r, beta.real(), beta.imag(), p));
+        MXG_TRY(apply_prec(c, A, o, p, y));
+        MXG_TRY(mxg_csr_apply(c, A, y, v));
+        cplx rhv;
+        MXG_TRY(cdot(rh, v, &rhv));
+        if (rhv == cplx(0.0)) { broke = true; break; }
+        alpha = rho / rhv;
+        MXG_TRY(mxg_mv_add(1.0, 0.0, r, -alpha.real(), -alpha.imag(), v, sv));      // s = r - alpha v
+        MXG_TRY(apply_prec(c, A, o, sv, z));
+        MXG_TRY(mxg_csr_apply(c, A, z, t));
+        cplx ts, tt;
+        MXG_TRY(cdot(t, sv, &ts));
+        MXG_TRY(cdot(t, t, &tt));
+        omega = tt == cplx(0.0) ? cplx(0.0) : ts / tt;
+        MXG_TRY(mxg_mv_axpby(alpha.real(), alpha.imag(), y, 1.0, 0.0, xj));         // x += alpha y + omega z
+        MXG_TRY(mxg_mv_axpby(omega.real(), omega.imag(), z, 1.0, 0.0, xj));
+        MXG_TRY(mxg_mv_add(1.0, 0.0, sv, -omega.real(), -omega.imag(), t, r));      // r = s - omega t
+        ++it;
+        MXG_TRY(mxg_mv_norm2(r, &rnorm));
+        if (!(rnorm == rnorm)) { broke = true; break; }
+      }
+      const double prev = res;
+      MXG_TRY(true_residual(c, A, bj, xj, r, &res));
+      if (!(res == res)) break;
+      if (broke && !(res < prev)) break;          // breakdown without progress: report what we have
+      if (!broke && rnorm > o->tol) break;        // iteration cap
+      if (!(res < prev) && res > o->tol) break;   // recurrence and true residual disagree, no progress
+    }
+    info->iters += it;
+    if (res > info->true_res) info->true_res = res;
+    if (!(res <= o->tol)) info->converged = 0;
+  }
+  return 0;
+}
+
 extern "C" int mxg_solve_gmres(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
                                const mxg_solve_opts* o, mxg_solve_info* info) {
   MXG_CHECK(c && A && b && x && o && info, "mxg_solve_gmres: NULL argument");

@@ -26,7 +26,7 @@ def _oracle_physical_modes(o, shift, want):
     return np.sort(out)[:want]
 
 
-@pytest.mark.parametrize("lin_type,prec", [("cg", "jacobi"), ("gmres", "none"), ("cg", "amg")])
+@pytest.mark.parametrize("lin_type,prec", [("cg", "jacobi"), ("gmres", "none"), ("cg", "amg"), ("bicgstab", "amg")])
 def test_pillbox16_eigenvalues_match_oracle(ctx, oracle_pillbox16, lin_type, prec):
     _, o = oracle_pillbox16
     shift = yee.default_shift([1, 1, 1])

@@ -17,7 +17,8 @@ def _system(o, shift):
     return A, used
 
 
-@pytest.mark.parametrize("method,precond", [("cg", "none"), ("cg", "jacobi"), ("gmres", "none"), ("gmres", "jacobi")])
+@pytest.mark.parametrize("method,precond", [("cg", "none"), ("cg", "jacobi"), ("gmres", "none"), ("gmres", "jacobi"),
+                                            ("bicgstab", "none"), ("bicgstab", "jacobi")])
 def test_shifted_veclapl_solve(ctx, oracle_pillbox12, rng, method, precond):
     """(vecLapl - shift dmA) x = dmA b, the first solve of MxMagWaveOp::Apply
     (src/MxMagWaveOp.cpp:865-885); unused rows are zero rows with zero right-hand side."""
@@ -52,8 +53,9 @@ def test_scalar_laplacian_solve_two_columns(ctx, oracle_pillbox12, rng):
     assert np.linalg.norm(S @ x.to_numpy() - rhs, axis=0).max() <= 2e-8
 
 
-def test_gmres_nonsymmetric_complex(ctx, rng):
-    """Config 5 flavour: non-Hermitian complex system (diagonally dominant)."""
+@pytest.mark.parametrize("method", ["gmres", "bicgstab"])
+def test_gmres_nonsymmetric_complex(ctx, rng, method):
+    """Config 5 flavour: non-Hermitian complex system (diagonally dominant); GMRES and BiCGStab (AZ_bicgstab)."""
     n = 4000
     R = sp.random(n, n, density=5.0 / n, random_state=3, format="csr")
     A = (sp.diags(np.full(n, 8.0 + 1.0j)) + R + 0.5j * sp.random(n, n, density=3.0 / n, random_state=4, format="csr")).tocsr()
@@ -62,7 +64,7 @@ def test_gmres_nonsymmetric_complex(ctx, rng):
     dev = mx.CsrMatrix.from_scipy(ctx, A)
     b = mx.MultiVec.from_numpy(ctx, rhs)
     x = mx.MultiVec(ctx, n, 1, True)
-    iters, conv, res = dev.solve(b, x, method="gmres", tol=1e-10, restart=30)
+    iters, conv, res = dev.solve(b, x, method=method, tol=1e-10, restart=30)
     assert conv
     assert np.linalg.norm(A @ x.to_numpy()[:, 0] - rhs) <= 2e-10
 
