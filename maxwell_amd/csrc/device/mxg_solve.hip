@@ -500,6 +500,14 @@ int mg_apply_nocopy(mxg_ctx* c, mxg_mg* mg, mxg_mv* r, mxg_mv** z_out) {
   return rc;
 }
 
+// z = M^-1 v where the caller only reads the result before the next application: with the multigrid (real
+// scalars) *zc points at the hierarchy's own vector, otherwise at z
+int prec_view(mxg_ctx* c, const mxg_csr* A, const mxg_solve_opts* o, mxg_mv* v, mxg_mv* z, mxg_mv** zc) {
+  if (o->precond == 3 && o->mg && !v->is_complex) return mg_apply_nocopy(c, o->mg, v, zc);
+  *zc = z;
+  return apply_prec(c, A, o, v, z);
+}
+
 bool cg_fused_ok(const mxg_csr* A, const mxg_solve_opts* o) {
   return !A->is_complex && A->pipe_geo == 10 && A->npipe > 0 && (A->kernel & 0x30000) &&
          (o->precond <= 1 || (o->precond == 3 && o->mg != nullptr));
@@ -760,8 +768,9 @@ extern "C" int mxg_solve_gmres(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mx
       int j = 0;
       double est = beta;
       for (; j < m && it < max_iters; ++j) {
-        MXG_TRY(apply_prec(c, A, o, vcol[j], z));
-        MXG_TRY(mxg_csr_apply(c, A, z, wv));
+        mxg_mv* zc;
+        MXG_TRY(prec_view(c, A, o, vcol[j], z, &zc));
+        MXG_TRY(mxg_csr_apply(c, A, zc, wv));
         ++it;
         // CGS2: h = V^H w; w -= V h; h2 = V^H w; w -= V h2; h += h2
         MXG_TRY(mxg_mv_trans_mv(1.0, 0.0, vlead[j], wv, hbuf.data(), j + 1));
@@ -810,8 +819,9 @@ extern "C" int mxg_solve_gmres(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mx
           else hbuf[i] = yv[i].real();
         }
         MXG_TRY(mxg_mv_times_mat(1.0, 0.0, vlead[jj - 1], hbuf.data(), jj, jj, 1, 0.0, 0.0, wv));
-        MXG_TRY(apply_prec(c, A, o, wv, z));
-        MXG_TRY(mxg_mv_axpby(1.0, 0.0, z, 1.0, 0.0, xj));
+        mxg_mv* zc;
+        MXG_TRY(prec_view(c, A, o, wv, z, &zc));
+        MXG_TRY(mxg_mv_axpby(1.0, 0.0, zc, 1.0, 0.0, xj));
       }
       const double prev = res;
       MXG_TRY(true_residual(c, A, bj, xj, r, &res));
