@@ -236,6 +236,10 @@ def main():
                 os.write(json_fd, (json.dumps(out) + "\n").encode())
             os._exit(0)
 
+        try:
+            sim.close()          # the window operators of the SpMV workload (host memory) are not needed any more
+        except Exception:
+            pass
         dog = threading.Timer(args.eig_timeout, bail)
         dog.daemon = True
         dog.start()
