@@ -55,9 +55,11 @@ class LocalWorld:
             t.start()
         for t in threads:
             t.join()
-        for e in err:
-            if e is not None:
-                raise e
+        failed = [(r, e) for r, e in enumerate(err) if e is not None]
+        if failed:
+            # the rank that failed first matters: the others usually only report that it never reached a collective
+            first = [f for f in failed if "did not reach the collective" not in str(f[1])] or failed
+            raise MxError("rank %d: %s: %s" % (first[0][0], type(first[0][1]).__name__, first[0][1])) from first[0][1]
         return out
 
     def close(self):

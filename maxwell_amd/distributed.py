@@ -68,7 +68,9 @@ class BoxSim(Sim):
                                       C.byref(rp), C.byref(cg), C.byref(va), C.byref(rg), C.byref(nown),
                                       C.byref(co), C.byref(ncomp)), self.lib, "mxh")
         def arr(p, n):
-            return np.ctypeslib.as_array(p, (max(n, 1),))[:n].copy()
+            if n == 0 or not p:
+                return np.zeros(0, dtype=p._type_)
+            return np.ctypeslib.as_array(p, (n,)).copy()
         return dict(rowptr=arr(rp, nr.value + 1), colgid=arr(cg, nz.value), vals=arr(va, nz.value),
                     rowgid=arr(rg, nr.value), colowned=arr(co, nown.value), ncomp=ncomp.value)
 
@@ -190,8 +192,8 @@ class DistMatrix:
                                      C.byref(nc), C.byref(cg), C.byref(ng)), lib, "mxh")
         self.h = A
         self.nrows, self.ncols_owned, self.nghost = nr.value, nc.value, ng.value
-        self.row_gids = np.ctypeslib.as_array(rg, (max(nr.value, 1),))[:nr.value].copy()
-        self.col_gids = np.ctypeslib.as_array(cg, (max(nc.value, 1),))[:nc.value].copy()
+        self.row_gids = np.ctypeslib.as_array(rg, (nr.value,)).copy() if nr.value else np.zeros(0, np.int64)
+        self.col_gids = np.ctypeslib.as_array(cg, (nc.value,)).copy() if nc.value else np.zeros(0, np.int64)
 
     def apply(self, x, y):
         _chk(self.ctx.lib.mxg_csr_apply(self.ctx.h, self.h, x.h, y.h), self.ctx.lib)

@@ -271,3 +271,28 @@ def test_odd_grids_and_rank_counts(ctx, n, nranks):
     out = _run_ranks(nranks, rank)
     assert all(o == out[0] for o in out) and len(out[0]) == 3
     assert np.abs(np.sort(out[0]) - k1).max() / np.abs(k1).max() < 1e-8
+
+
+def test_ranks_that_own_nothing(ctx):
+    """A small cavity in one corner of the grid: three of the four MxGridDomain boxes lie in the metal and own no
+    unknown at all (empty maps, empty matrices, empty multigrid levels) - they still take part in every collective."""
+    kw = dict(origin=(-0.5,) * 3, size=(1.0,) * 3, lower=("pec",) * 3, upper=("pec",) * 3,
+              pec_shape="sphere(0.21;-0.25,-0.25,-0.25)")
+    par = dict(nev=2, basis=20, tol=1e-9, shift=30.0, lin_type="cg", lin_tol=1e-10, prec_type="amg")
+    s1 = mx.Solver(ctx, mx.Sim(16, **kw), mx.SolverParams(**par))
+    assert s1.solve() == 2
+    k1 = np.sort([s1.result(i)["k2"].real for i in range(2)])
+
+    def rank(c):
+        sim = mxd.BoxSim(16, c.rank, 4, **kw)
+        rows = len(sim.dist_op("shifted", 30.0)["rowgid"])
+        s = mx.Solver(c, sim, mx.SolverParams(**par))
+        n = s.solve()
+        res = [s.result(i)["k2"].real for i in range(n)]
+        s.close()
+        return rows, res
+
+    out = _run_ranks(4, rank)
+    assert sorted(o[0] for o in out)[:3] == [0, 0, 0] and max(o[0] for o in out) > 0
+    assert all(o[1] == out[0][1] for o in out)
+    assert np.abs(np.sort(out[0][1]) - k1).max() / k1.max() < 1e-7
