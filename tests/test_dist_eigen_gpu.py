@@ -296,3 +296,26 @@ def test_ranks_that_own_nothing(ctx):
     assert sorted(o[0] for o in out)[:3] == [0, 0, 0] and max(o[0] for o in out) > 0
     assert all(o[1] == out[0][1] for o in out)
     assert np.abs(np.sort(out[0][1]) - k1).max() / k1.max() < 1e-7
+
+
+@pytest.mark.parametrize("lin_type,block", [("cg", 2), ("bicgstab", 1)])
+def test_decomposed_block_and_bicgstab(ctx, oracle_pillbox16, lin_type, block):
+    """Block size 2 (two-column products with ghost import, block orthogonalisation with all-reduced Gram matrices)
+    and the BiCGStab inner solver on 2 boxes."""
+    from tests.test_eigen_gpu import _oracle_physical_modes, REL_TOL
+    _, o = oracle_pillbox16
+    shift = yee.default_shift([1, 1, 1])
+    want = _oracle_physical_modes(o, shift, 4)
+    kw = dict(nev=4, basis=20, tol=1e-10, shift=shift, lin_type=lin_type, lin_tol=1e-11, prec_type="amg", block_size=block)
+
+    def rank(c):
+        s = mx.Solver(c, mxd.BoxSim(16, c.rank, 2, pec_shape=PILLBOX_SHAPE, **BOX), mx.SolverParams(**kw))
+        n = s.solve()
+        res = [s.result(i)["k2"].real for i in range(n)]
+        s.close()
+        return res
+
+    out = _run_ranks(2, rank)
+    assert out[0] == out[1] and len(out[0]) >= 4
+    k2 = np.sort(out[0])[:4]
+    assert np.abs(k2 - want).max() / np.abs(want).max() < REL_TOL, (k2, want)
