@@ -319,3 +319,26 @@ def test_decomposed_block_and_bicgstab(ctx, oracle_pillbox16, lin_type, block):
     assert out[0] == out[1] and len(out[0]) >= 4
     k2 = np.sort(out[0])[:4]
     assert np.abs(k2 - want).max() / np.abs(want).max() < REL_TOL, (k2, want)
+
+
+def test_setup_collectives_over_rccl_one_rank(built):
+    """The setup-time collectives of include/mxg.h on a real RCCL communicator (a world of one rank - RCCL refuses two
+    ranks on the one test GPU): all-gather of an int64, of variable-length byte strings, all-reduce of host doubles."""
+    import ctypes as C
+    from maxwell_amd import _lib
+    c = mx.Ctx(0, 0, 1, mx.Ctx.unique_id())
+    try:
+        lib = c.lib
+        out = (C.c_int64 * 1)()
+        assert lib.mxg_comm_allgather_i64(c.h, 41, out) == 0 and out[0] == 41
+        data = np.arange(1000, dtype=np.int64) * 3 + 1
+        counts = (C.c_int64 * 1)(data.nbytes)
+        recv = np.zeros_like(data)
+        assert lib.mxg_comm_allgatherv(c.h, data.ctypes.data_as(C.c_void_p), data.nbytes, counts, recv.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(recv, data)
+        v = np.array([1.5, -2.25, 1e300])
+        assert lib.mxg_comm_allreduce_host(c.h, v.ctypes.data_as(_lib.c_dp), 3) == 0
+        assert np.array_equal(v, [1.5, -2.25, 1e300])
+        c.barrier()
+    finally:
+        c.close()
