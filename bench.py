@@ -248,6 +248,8 @@ def main():
         except Exception as e:
             out["eigen"] = {"error": str(e)}
         dog.cancel()
+    import resource
+    log("rank %d host peak RSS %.1f GiB" % (rank, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2.0 ** 20))
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
