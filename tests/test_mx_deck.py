@@ -191,3 +191,96 @@ def test_complex_inverse_permittivity_with_bloch_phases():
     deck, prob = _complex_ops_same(text, strict=False)
     ie = prob.op("invEps")
     assert np.abs(ie.data.imag).max() > 1e-3
+
+
+def _random_shape_xml(rng, depth, counter):
+    """A random CSG tree in deck syntax over every shape tag of src/MxProblem.cpp:8-17, with random transforms."""
+    def vec(lo, hi, n=3):
+        return "[" + ", ".join("%.4f" % v for v in rng.uniform(lo, hi, n)) + "]"
+
+    def transforms():
+        out = []
+        for _ in range(int(rng.integers(0, 3))):
+            kind = rng.choice(["Translate", "Rotate", "Scale", "Reflect"])
+            if kind == "Translate":
+                out.append("<Translate>\n vector = %s\n</Translate>" % vec(-0.15, 0.15))
+            elif kind == "Rotate":
+                out.append("<Rotate>\n axis = %s\n angle = %.4f\n</Rotate>" % (vec(-1, 1), rng.uniform(-1, 1)))
+            elif kind == "Scale":
+                out.append("<Scale>\n magnitudes = %s\n</Scale>" % vec(0.7, 1.3))
+            else:
+                out.append("<Reflect>\n normal = %s\n point in plane = %s\n</Reflect>" % (vec(-1, 1), vec(-0.1, 0.1)))
+        return "\n".join(out)
+
+    counter[0] += 1
+    name = "s%d" % counter[0]
+    leaf = depth == 0 or rng.random() < 0.35
+    inv = "\n invert = true" if rng.random() < 0.15 else ""
+    if leaf:
+        kind = rng.choice(["Sphere", "Cylinder", "Slab", "HalfSpace", "Ellipsoid", "Torus", "Cone"])
+        body = {"Sphere": "radius = %.4f" % rng.uniform(0.15, 0.45),
+                "Cylinder": "radius = %.4f\n axis = %s" % (rng.uniform(0.1, 0.4), vec(-1, 1)),
+                "Slab": "thickness = %.4f\n normal = %s" % (rng.uniform(0.1, 0.6), vec(-1, 1)),
+                "HalfSpace": "normal = %s" % vec(-1, 1),
+                "Ellipsoid": "axes = %s" % vec(0.15, 0.45),
+                "Torus": "major radius = %.4f\n minor radius = %.4f\n axis = %s" % (rng.uniform(0.2, 0.35), rng.uniform(0.05, 0.12), vec(-1, 1)),
+                "Cone": "angle = %.4f\n axis = %s" % (rng.uniform(0.3, 1.2), vec(-1, 1))}[kind]
+        return "<%s>\n name = %s%s\n %s\n%s\n</%s>" % (kind, name, inv, body, transforms(), kind)
+    kind = rng.choice(["ShapeIntersection", "ShapeUnion", "ShapeSubtract", "ShapeMirror", "ShapeRepeat"])
+    if kind in ("ShapeIntersection", "ShapeUnion"):
+        kids = "\n".join(_random_shape_xml(rng, depth - 1, counter) for _ in range(int(rng.integers(2, 4))))
+        return "<%s>\n name = %s%s\n%s\n%s\n</%s>" % (kind, name, inv, kids, transforms(), kind)
+    if kind == "ShapeSubtract":
+        kids = "\n".join(_random_shape_xml(rng, depth - 1, counter) for _ in range(2))
+        return "<ShapeSubtract>\n name = %s%s\n%s\n%s\n</ShapeSubtract>" % (name, inv, kids, transforms())
+    kid = _random_shape_xml(rng, depth - 1, counter)
+    if kind == "ShapeMirror":
+        return "<ShapeMirror>\n name = %s%s\n normal = %s\n point in plane = %s\n%s\n%s\n</ShapeMirror>" % (
+            name, inv, vec(-1, 1), vec(-0.1, 0.1), kid, transforms())
+    return ("<ShapeRepeat>\n name = %s%s\n origin = %s\n direction = %s\n step = %.4f\n pos steps = %d\n neg steps = %d\n%s\n%s\n"
+            "</ShapeRepeat>" % (name, inv, vec(-0.1, 0.1), vec(-1, 1), rng.uniform(0.2, 0.5), rng.integers(0, 3),
+                                rng.integers(0, 3), kid, transforms()))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_csg_trees_bit_identical(seed):
+    """Random trees over all twelve shape tags with random transforms on primitives and composites: the C++ factory
+    (include/mx/MxProblem.h + mx_geometry.cpp) and the oracle's (oracle/mxdeck.py + geometry.py) give the same level
+    set bit for bit at random points - the composition rules of src/MxShape{Union,Subtract,Mirror,Repeat}.hpp and the
+    transform order of src/MxShape.cpp:30-60 are exercised far beyond the hand-written decks."""
+    rng = np.random.default_rng(1000 + seed)
+    shape = _random_shape_xml(rng, 3, [0])
+    text = ("<S>\n polarization = TE\n <Grid>\n resolution = [4, 4, 4]\n origin = [-0.5, -0.5, -0.5]\n </Grid>\n"
+            " <PEC>\n%s\n </PEC>\n</S>" % shape)
+    deck = mxdeck.Deck(text)
+    prob = mx.Problem(text=text)
+    pts = rng.uniform(-0.6, 0.6, (600, 3))
+    want = deck.pec.func(pts)
+    got = np.array([prob.pec_func(p) for p in pts])
+    ok = np.isfinite(want)
+    assert np.array_equal(got[ok], want[ok]), shape
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    scalar = np.array([deck.pec.func1(tuple(p)) for p in pts[:100].tolist()])
+    assert np.array_equal(scalar[ok[:100]], want[:100][ok[:100]])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_csg_assembly_bit_identical(seed):
+    """The same random trees as PEC surfaces of a small grid: cut-cell fractions need the composite shapes' gradients
+    (Newton steps of the root finder) - every assembled operator equals the oracle's bit for bit."""
+    rng = np.random.default_rng(5000 + seed)
+    shape = _random_shape_xml(rng, 2, [0])
+    text = ("<S>\n polarization = TE\n <Grid>\n resolution = [6, 5, 7]\n origin = [-0.52, -0.5, -0.49]\n </Grid>\n"
+            " <BoundaryConditions>\n lower bcs = [pec, pec, pec]\n upper bcs = [pec, pec, pec]\n </BoundaryConditions>\n"
+            " <PEC>\n%s\n </PEC>\n</S>" % shape)
+    deck = mxdeck.Deck(text)
+    ops = deck.sim().wave_ops()
+    sim = mx.Problem(text=text).sim()
+    for opname, ref in ops.items():
+        a, b = sim.op(opname).tocsr(), ref.tocsr()
+        assert a.shape == b.shape, opname
+        d = a - b
+        if d.nnz:
+            bad = np.abs(d.data)
+            assert np.all((bad == 0.0) | np.isnan(bad)), (opname, shape)      # NaN fractions (degenerate cuts) on both sides
+            assert np.array_equal(np.isnan(a.toarray()), np.isnan(b.toarray())), opname
