@@ -284,3 +284,30 @@ def test_random_csg_assembly_bit_identical(seed):
             bad = np.abs(d.data)
             assert np.all((bad == 0.0) | np.isnan(bad)), (opname, shape)      # NaN fractions (degenerate cuts) on both sides
             assert np.array_equal(np.isnan(a.toarray()), np.isnan(b.toarray())), opname
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_dielectric_shapes_bit_identical(seed):
+    """Random composite shapes as (anisotropic) dielectrics: the FIT inverse permittivity takes the interface normal from
+    the composite's gradient (src/MxYeeFitInvEps.cpp stencil normal) - invEps, invEpsVolAve and every product equal the
+    oracle's bit for bit."""
+    rng = np.random.default_rng(9000 + seed)
+    shape = _random_shape_xml(rng, 2, [0])
+    diag = rng.uniform(2.0, 12.0, 3)
+    off = rng.uniform(-0.4, 0.4, 3) if seed % 2 else np.zeros(3)
+    text = ("<S>\n polarization = TE\n <Grid>\n resolution = [6, 6, 5]\n origin = [-0.5, -0.52, -0.49]\n </Grid>\n"
+            " <BoundaryConditions>\n lower bcs = [pec, pmc, periodic]\n upper bcs = [pec, pec, periodic]\n </BoundaryConditions>\n"
+            " <Dielectric>\n name = blob\n eps diag = [%r, %r, %r]\n eps off diag = [%r, %r, %r]\n%s\n </Dielectric>\n</S>"
+            % tuple([float(v) for v in diag] + [float(v) for v in off] + [shape]))
+    deck = mxdeck.Deck(text)
+    ops = deck.sim().wave_ops()
+    sim = mx.Problem(text=text).sim()
+    assert "invEps" in ops
+    for opname, ref in ops.items():
+        a, b = sim.op(opname).tocsr(), ref.tocsr()
+        assert a.shape == b.shape, opname
+        d = a - b
+        if d.nnz:
+            bad = np.abs(d.data)
+            assert np.all((bad == 0.0) | np.isnan(bad)), (opname, float(np.nanmax(bad)), shape)
+            assert np.array_equal(np.isnan(a.toarray()), np.isnan(b.toarray())), opname
