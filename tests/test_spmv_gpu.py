@@ -243,6 +243,17 @@ def test_halo_exchange_on_a_one_rank_communicator(built, oracle_pillbox12, rng):
         A.set_kernel(0x750000)
         A.apply(X, Y)
         assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+        # compressed stream on the ghosted matrix: interior blocks first, boundary blocks read the ghost buffer after
+        # the exchange (k_spmv_cs<..., HALO>), over real ncclSend/ncclRecv; two columns take the packed-x route
+        nb, nfall, _ = A.compress()
+        assert nb > 0
+        for rep in range(2):
+            x3 = rng.uniform(-1, 1, (n, 1))
+            X3 = mx.MultiVec.from_numpy(ctx1, x3); Y3 = mx.MultiVec(ctx1, n, 1)
+            A.apply(X3, Y3)
+            assert np.array_equal(Y3.to_numpy(), cref.spmv(m, x3))
+        A.apply(X, Y)
+        assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
         # fused CG (SpMV + dot with the halo in flight) on the ghosted matrix
         spd = (m + m.T).tocsr() * 0.5 + sp.identity(n) * 40.0
         cols2 = spd.indices.astype(np.int64).copy()
@@ -257,6 +268,10 @@ def test_halo_exchange_on_a_one_rank_communicator(built, oracle_pillbox12, rng):
         Bv = mx.MultiVec.from_numpy(ctx1, bvec); Xs = mx.MultiVec(ctx1, n, 1); Xs.fill(0.0)
         it, conv, res = S.solve(Bv, Xs, method="cg", tol=1e-10, precond="jacobi")
         assert conv and np.linalg.norm(spd @ Xs.to_numpy()[:, 0] - bvec) < 1e-8
+        S.compress()                       # the same solve from the compressed stream (fused p.Ap with ghosts)
+        Xs.fill(0.0)
+        it2, conv2, _ = S.solve(Bv, Xs, method="cg", tol=1e-10, precond="jacobi")
+        assert conv2 and abs(it2 - it) <= 2 and np.linalg.norm(spd @ Xs.to_numpy()[:, 0] - bvec) < 1e-8
         S.close()
         # the collectives of C2 on the same communicator
         assert np.abs(X.norm2() - np.linalg.norm(x, axis=0)).max() < 1e-12
