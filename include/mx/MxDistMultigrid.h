@@ -58,7 +58,10 @@ class MxDistMultigrid {
     for (auto& m : mR) r.push_back(m->getRawMatrix());
     MX_ABI(mxg_mg_create(comm->getCtx(), (int)a.size(), a.data(), p.data(), r.data(), sweeps, sweeps, coarseSweeps, omega,
                          coarseScale, &mMg), "MxDistMultigrid");
-    if (np > 1) replicateTail(dims, minCoarse, maxLevels - (int)mA.size() + 1, sweeps, coarseSweeps, omega, coarseScale);
+    // (one rank: only when asked for - MXG_DIST_MG=force runs this class on a single rank, which is how the gathered
+    // levels and their all-gather are exercised over a one-rank RCCL communicator in the tests)
+    if (np > 1 || (getenv("MXG_DIST_MG") && std::string(getenv("MXG_DIST_MG")) == "force"))
+      replicateTail(dims, minCoarse, maxLevels - (int)mA.size() + 1, sweeps, coarseSweeps, omega, coarseScale);
   }
   ~MxDistMultigrid() {
     if (mMg) mxg_mg_destroy(mMg);

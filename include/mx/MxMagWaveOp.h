@@ -359,7 +359,8 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mVecMgMatrix = realPart(mShiftedVecLapl);
     if (mHasCurlNull && mScaMgMatrix.is_null()) mScaMgMatrix = realPart(mScaLapl);
     static const bool blockMg = getenv("MXG_DIST_MG") && std::string(getenv("MXG_DIST_MG")) == "block";
-    if (mSim->isDistributed() && !blockMg) {
+    static const bool forceDist = getenv("MXG_DIST_MG") && std::string(getenv("MXG_DIST_MG")) == "force";
+    if ((mSim->isDistributed() && !blockMg) || forceDist) {
       // the single-rank hierarchy, every level row-partitioned over the MxGridDomain boxes (MxDistMultigrid.h)
       mVecDmg.reset(new MxDistMultigrid(mVecMgMatrix, 3, a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9));
       if (mHasCurlNull && !mScaDmg)

@@ -342,3 +342,38 @@ def test_setup_collectives_over_rccl_one_rank(built):
         c.barrier()
     finally:
         c.close()
+
+
+def test_partitioned_multigrid_class_on_one_rccl_rank(built, tmp_path):
+    """MXG_DIST_MG=force: the row-partitioned multigrid class (coarsening by lattice ids, plan agreement per level,
+    gathered levels with their all-gather per V-cycle) on ONE rank over a real RCCL communicator.  With one rank it must
+    reproduce the single-rank hierarchy: same inner iteration counts and eigenvalues as the default path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np, maxwell_amd as mx\n"
+        "c = mx.Ctx(0, 0, 1, mx.Ctx.unique_id())\n"
+        "s = mx.Solver(c, mx.Sim.pillbox(32), mx.SolverParams(nev=3, basis=20, tol=1e-9, shift=0.05 * (2 * np.pi) ** 2, "
+        "lin_type='cg', lin_tol=1e-10, prec_type='amg'))\n"
+        "n = s.solve(); st = s.stats()\n"
+        "print('RESULT ' + json.dumps(dict(k2=[s.result(i)['k2'].real for i in range(n)], vec=st['vec_iters'], sca=st['sca_iters'])))\n"
+        % root)
+    out = {}
+    for mode in ("default", "force"):
+        env = dict(os.environ)
+        env.pop("MXG_DIST_MG", None)
+        if mode == "force":
+            env["MXG_DIST_MG"] = "force"
+            env["MXG_DIST_MG_REPLICATE"] = "20000"      # two partitioned levels above the gathered ones at 32^3
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+        out[mode] = json.loads(line[0][7:])
+    assert len(out["force"]["k2"]) == 3
+    assert np.allclose(out["force"]["k2"], out["default"]["k2"], rtol=1e-9)
+    assert abs(out["force"]["vec"] - out["default"]["vec"]) <= 0.03 * out["default"]["vec"] + 2
+    assert abs(out["force"]["sca"] - out["default"]["sca"]) <= 0.03 * out["default"]["sca"] + 2
