@@ -77,10 +77,9 @@ class MxIO {
       std::snprintf(stem, sizeof stem, "mx%s_%s_vec%.2i", field.getFieldName().c_str(), name.c_str(), (int)vec);
       MX_ABI_H(mxh_field_write(stem, "real", dims, re.data(), written, sizeof written), "MxIO::save");
       out.push_back(written);
-      if (ScalarTraits<Scalar>::isComplex) {   // the reference puts "imag" into the same file; here: a second file
-        const std::string s2 = std::string(stem) + "_imag";
-        MX_ABI_H(mxh_field_write(s2.c_str(), "imag", dims, im.data(), written, sizeof written), "MxIO::save");
-        out.push_back(written);
+      if (ScalarTraits<Scalar>::isComplex) {   // "imag" next to "real" in the same file (src/MxIO.cpp:199-222); a second .npy without HDF5
+        MX_ABI_H(mxh_field_append(stem, "imag", dims, im.data(), written, sizeof written), "MxIO::save");
+        if (out.back() != written) out.push_back(written);
       }
     }
     return out;

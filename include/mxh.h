@@ -186,6 +186,9 @@ int mxh_problem_solver(mxg_ctx* ctx, mxh_problem* p, int verbose, mxh_solver** o
 int mxh_hdf5_available(void);
 int mxh_field_write(const char* stem, const char* dataset, const int64_t dims[4], const double* data,
                     char* written, size_t written_len);
+/* a further dataset in the same file ("imag" next to "real", src/MxIO.cpp:199-222); `<stem>_<dataset>.npy` without HDF5 */
+int mxh_field_append(const char* stem, const char* dataset, const int64_t dims[4], const double* data,
+                     char* written, size_t written_len);
 /* read a dataset back (dims always; data when non-NULL and capacity >= product of dims) */
 int mxh_field_read_h5(const char* path, const char* dataset, int64_t dims[4], double* data, int64_t capacity);
 

@@ -142,6 +142,7 @@ MXH_SIGNATURES = {
     "mxh_solver_eigvec": (C.c_int, [vp, C.c_int, vp]),
     "mxh_hdf5_available": (C.c_int, []),
     "mxh_field_write": (C.c_int, [C.c_char_p, C.c_char_p, c_i64p, c_dp, C.c_char_p, C.c_size_t]),
+    "mxh_field_append": (C.c_int, [C.c_char_p, C.c_char_p, c_i64p, c_dp, C.c_char_p, C.c_size_t]),
     "mxh_field_read_h5": (C.c_int, [C.c_char_p, C.c_char_p, c_i64p, c_dp, C.c_int64]),
     "mxh_problem_parse": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
     "mxh_problem_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),

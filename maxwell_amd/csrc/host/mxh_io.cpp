@@ -136,6 +136,38 @@ extern "C" int mxh_field_write(const char* stem, const char* dataset, const int6
   }
 }
 
+// a further dataset in the file mxh_field_write made (the reference keeps "real" and "imag" of a complex field in one
+// file, src/MxIO.cpp:199-222); without HDF5 the data goes to `<stem>_<dataset>.npy`
+extern "C" int mxh_field_append(const char* stem, const char* dataset, const int64_t dims[4], const double* data,
+                                char* written, size_t written_len) {
+  try {
+    if (!stem || !dataset || !dims || !data) throw std::runtime_error("mxh_field_append: NULL argument");
+    std::string path;
+    if (Hdf5* h = hdf5()) {
+      path = std::string(stem) + ".h5";
+      const unsigned long long d[4] = {(unsigned long long)dims[0], (unsigned long long)dims[1], (unsigned long long)dims[2],
+                                       (unsigned long long)dims[3]};
+      const int64_t file = h->id(h->Fopen(path.c_str(), 1u /* H5F_ACC_RDWR */, 0));
+      if (file < 0) throw std::runtime_error("H5Fopen (read-write) failed for '" + path + "'");
+      const int64_t space = h->id(h->Screate_simple(4, d, nullptr));
+      const int64_t dset = h->id(h->Dcreate2(file, dataset, h->native_double, space, 0, 0, 0));
+      int rc = dset < 0 ? -1 : h->Dwrite(dset, h->native_double, 0 /* H5S_ALL */, 0, 0, data);
+      if (dset >= 0) h->Dclose(dset);
+      if (space >= 0) h->Sclose(space);
+      h->Fclose(file);
+      if (rc < 0) throw std::runtime_error("HDF5 dataset write failed for '" + path + "'");
+    } else {
+      path = std::string(stem) + "_" + dataset + ".npy";
+      write_npy(path, dims, data);
+    }
+    if (written && written_len) { std::strncpy(written, path.c_str(), written_len - 1); written[written_len - 1] = '\0'; }
+    return 0;
+  } catch (const std::exception& e) {
+    mxh_set_error(e.what());
+    return 1;
+  }
+}
+
 extern "C" int mxh_field_read_h5(const char* path, const char* dataset, int64_t dims[4], double* data, int64_t capacity) {
   try {
     Hdf5* h = hdf5();

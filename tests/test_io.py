@@ -35,6 +35,16 @@ def test_hdf5_round_trip_when_a_library_is_present(tmp_path):
     assert lib.mxh_field_read_h5(path.encode(), b"real", dims, back.ctypes.data_as(_lib.c_dp), back.size) == 0
     assert list(dims) == [5, 4, 3, 3] and np.array_equal(back.reshape(arr.shape), arr)
     assert lib.mxh_field_read_h5(path.encode(), b"imag", dims, None, 0) != 0          # no such dataset
+    # a complex field keeps "imag" next to "real" in the same file (src/MxIO.cpp:199-222)
+    im = np.random.default_rng(1).uniform(-1, 1, arr.shape)
+    out = C.create_string_buffer(512)
+    d4 = (C.c_int64 * 4)(*arr.shape)
+    assert lib.mxh_field_append(str(tmp_path / "mxYeeFitBField_eigVecs_vec00").encode(), b"imag", d4, im.ctypes.data_as(_lib.c_dp), out, 512) == 0
+    assert out.value.decode() == path
+    assert lib.mxh_field_read_h5(path.encode(), b"imag", dims, back.ctypes.data_as(_lib.c_dp), back.size) == 0
+    assert np.array_equal(back.reshape(arr.shape), im)
+    assert lib.mxh_field_read_h5(path.encode(), b"real", dims, back.ctypes.data_as(_lib.c_dp), back.size) == 0
+    assert np.array_equal(back.reshape(arr.shape), arr)
 
 
 def test_npy_fallback_without_hdf5(tmp_path):
