@@ -289,7 +289,7 @@ def eigen_bench(mx, ctx, n):
 def eigen_bench_dist(mx, ctx, n, dist):
     """The N = 1 eigen problem (pillbox n^3) on a decomposed grid - STRONG scaling, unlike the SpMV line: one rank per
     MxGridDomain box (src/MxGrid.cpp:171-193), row-partitioned operators with RCCL ghost import, all-reduced inner
-    products, multigrid levels row-partitioned down to 1e5 rows and replicated below."""
+    products, multigrid levels row-partitioned down to 4e5 rows and replicated below."""
     from maxwell_amd import distributed as mxd
     from maxwell_amd.api import PILLBOX_SHAPE
     world, rank = ctx.nranks, ctx.rank
@@ -315,7 +315,7 @@ def eigen_bench_dist(mx, ctx, n, dist):
     pg = sim.proc_grid
     return {"workload": "pillbox %d^3 on %dx%dx%d MxGridDomain boxes (the N = 1 problem: strong scaling), nev 5, tol 1e-8, block "
                         "Krylov-Schur shift-invert, multigrid-preconditioned CG inner solves (tol 1e-9), levels row-partitioned "
-                        "above 1e5 rows" % (n, pg[0], pg[1], pg[2]),
+                        "above 4e5 rows" % (n, pg[0], pg[1], pg[2]),
             "scaling": "strong", "assembly_seconds": round(asm, 2), "solver_setup_seconds": round(setup, 2),
             "eigenpairs_per_s": round(nconv / secs, 4), "converged": nconv,
             "eigensolve_seconds": round(secs, 3), "applies": st["applies"], "vec_lin_iters": st["vec_iters"],

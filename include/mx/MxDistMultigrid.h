@@ -40,7 +40,9 @@ class MxDistMultigrid {
     int level = 0;
     // levels above this many global rows are row-partitioned; below, the hierarchy continues replicated on every
     // rank (one all-gather per V-cycle instead of a latency-bound ghost import per sweep and level)
-    int64_t replicateBelow = 100000;
+    // (4e5: at 256^3 .. 512^3 cells the levels of 2e7 and 2.6e6 rows stay partitioned; the 3.3e5-row level costs a rank
+    // ~15 us per product when replicated, less than one latency-bound ghost import)
+    int64_t replicateBelow = 400000;
     if (const char* e = getenv("MXG_DIST_MG_REPLICATE")) replicateBelow = atoll(e);
     while ((int)mA.size() < maxLevels &&
            (int64_t)mA.back()->getRangeMap()->getGlobalNumIndices() > std::max(minCoarse, replicateBelow)) {
