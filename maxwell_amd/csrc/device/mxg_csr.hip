@@ -930,6 +930,12 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
     // 7-point bulk rows of the vector Laplacian; 70.8 % of HBM peak at 256^3)
     MXG_TRY(build_pipe_desc(a, 10, rowptr));
     a->kernel = MXG_KERNEL_DEFAULT;
+  } else if (!a->is_complex) {
+    // a rank of a decomposed grid that owns nothing: same kernel family as everybody else (zero row blocks), so that
+    // every rank takes the same solver path and issues the same sequence of collectives
+    a->kernel = MXG_KERNEL_DEFAULT;
+    a->pipe_geo = 10;
+    a->npipe = 0;
   }
   *out = a;
   return 0;
@@ -1621,7 +1627,12 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
 int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out) {
   MXG_CHECK(!a->is_complex && x->k == 1 && y->k == 1 && a->nrows == a->ncols_owned,
             "mxg_dev_csr_apply_dot: real square single-column case only");
-  MXG_CHECK(a->pipe_geo == 10 && a->npipe > 0, "mxg_dev_csr_apply_dot: row-gather descriptors missing");
+  MXG_CHECK(a->pipe_geo == 10, "mxg_dev_csr_apply_dot: row-gather descriptors missing");
+  if (a->npipe == 0) {              // no rows on this rank: take part in the ghost import (nothing to send), x . y = 0
+    if (a->nneigh > 0) { MXG_TRY(halo_start(c, a, x)); MXG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0)); }
+    MXG_HIP(hipMemsetAsync(d_out, 0, sizeof(double), c->stream));
+    return 0;
+  }
   MvDesc X = x->desc();
   const MvDesc Y = y->desc();
   if (!a->d_dotpartial) MXG_HIP(hipMalloc(&a->d_dotpartial, sizeof(double) * a->npipe));

@@ -89,7 +89,7 @@ int true_residual(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, const mxg_mv* x
 // Every CHUNK iterations r.r comes to the host for the convergence test (unscaled 2-norm).
 // ------------------------------------------------------------------------------------------
 constexpr int CGB = 256;
-enum { S_RZ0 = 0, S_RZ1 = 1, S_PQ = 2, S_RR = 3 };
+enum { S_RZ0 = 0, S_RR = 1, S_RZ1 = 2, S_PQ = 3 };   // r.r sits between the two r.z slots: one all-reduce covers both
 
 __global__ void k_cg_update(long long n, double* __restrict__ x, double* __restrict__ r,
                             const double* __restrict__ p, const double* __restrict__ q,
@@ -509,7 +509,8 @@ int prec_view(mxg_ctx* c, const mxg_csr* A, const mxg_solve_opts* o, mxg_mv* v, 
 }
 
 bool cg_fused_ok(const mxg_csr* A, const mxg_solve_opts* o) {
-  return !A->is_complex && A->pipe_geo == 10 && A->npipe > 0 && (A->kernel & 0x30000) &&
+  // (must not depend on how many rows THIS rank owns: every rank of a decomposed grid has to take the same path)
+  return !A->is_complex && A->pipe_geo == 10 && (A->kernel & 0x30000) &&
          (o->precond <= 1 || (o->precond == 3 && o->mg != nullptr));
 }
 
@@ -556,10 +557,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
           MXG_TRY(mgprecond());
           MXG_TRY(mxg_dev_dot(c, r->desc(), zc->desc(), scal + nxt));
         }
-        if (mxg_comm_on(c)) {   // r.z and r.r sit in different slots: two tiny all-reduces
-          MXG_TRY(allreduce(scal + nxt, 1));
-          MXG_TRY(allreduce(scal + S_RR, 1));
-        }
+        if (mxg_comm_on(c)) MXG_TRY(allreduce(scal + std::min(nxt, (int)S_RR), 2));   // r.z (slot nxt) and r.r, adjacent
         hipLaunchKernelGGL(k_cg_dir, dim3(grid), dim3(CGB), 0, c->stream, n, p->colptr(0),
                            (const double*)zc->colptr(0), (const double*)scal, cur, nxt);
         cur = nxt;
