@@ -21,6 +21,8 @@ struct mxg_local_world {
   std::vector<std::vector<Send>> sends;                 // per rank: sends of the current exchange, in issue order
   std::vector<const void*> gptr;                        // per rank: all-gather source
   std::vector<int64_t> gcnt;
+  std::vector<int> opkind;                              // per rank: which collective it is in (checked at the rendezvous:
+  std::vector<long long> opsize;                        //  over RCCL a mismatch would be a hang, here it is an error)
   // every rank calls the collectives in the same order; a rank that never arrives (it failed) breaks the
   // world for everyone after the time limit instead of hanging the process
   int barrier() {
@@ -42,6 +44,8 @@ extern "C" int mxg_local_world_create(int nranks, mxg_local_world** out) {
   w->sends.resize(nranks);
   w->gptr.assign(nranks, nullptr);
   w->gcnt.assign(nranks, 0);
+  w->opkind.assign(nranks, 0);
+  w->opsize.assign(nranks, 0);
   *out = w;
   return 0;
 }
@@ -61,6 +65,22 @@ extern "C" int mxg_ctx_create_local(int device, int rank, int nranks, mxg_local_
   (*out)->lw = nranks > 1 ? w : nullptr;
   return 0;
 }
+
+// every rank announces the collective it is entering; after the rendezvous they must all agree
+#define MXG_LW_ENTER(w, c, kind, size)                                                                          \
+  do {                                                                                                          \
+    (w)->opkind[(c)->rank] = (kind);                                                                            \
+    (w)->opsize[(c)->rank] = (long long)(size);                                                                 \
+  } while (0)
+#define MXG_LW_AGREE(w, c, what, check_size)                                                                    \
+  do {                                                                                                          \
+    for (int r_ = 0; r_ < (w)->n; ++r_)                                                                         \
+      if ((w)->opkind[r_] != (w)->opkind[(c)->rank] || ((check_size) && (w)->opsize[r_] != (w)->opsize[(c)->rank])) { \
+        mxg_set_error("%s: rank %d is in collective %d (size %lld), rank %d in %d (size %lld): the ranks diverged", what, \
+                      (c)->rank, (w)->opkind[(c)->rank], (w)->opsize[(c)->rank], r_, (w)->opkind[r_], (w)->opsize[r_]); \
+        return 1;                                                                                               \
+      }                                                                                                         \
+  } while (0)
 
 #define MXG_LW_BARRIER(w)                                                                  \
   do {                                                                                     \
@@ -84,7 +104,9 @@ int mxg_comm_allreduce(mxg_ctx* c, double* d, size_t count, hipStream_t s) {
   mine.resize(count);
   MXG_HIP(hipMemcpyAsync(mine.data(), d, sizeof(double) * count, hipMemcpyDeviceToHost, s));
   MXG_HIP(hipStreamSynchronize(s));
+  MXG_LW_ENTER(w, c, 1, count);
   MXG_LW_BARRIER(w);
+  MXG_LW_AGREE(w, c, "all-reduce", true);
   std::vector<double> sum(count, 0.0);
   for (int r = 0; r < w->n; ++r) {          // rank order: every rank forms the same sum bit for bit
     MXG_CHECK(w->red[r].size() == count, "all-reduce: rank %d brought %zu values, rank %d %zu", r, w->red[r].size(),
@@ -115,7 +137,9 @@ int mxg_comm_exchange(mxg_ctx* c, const MxgXfer* x, int n, hipStream_t s) {
   mine.clear();
   for (int i = 0; i < n; ++i)
     if (x[i].ns > 0) mine.push_back({x[i].peer, x[i].send, x[i].ns});
+  MXG_LW_ENTER(w, c, 2, 0);
   MXG_LW_BARRIER(w);
+  MXG_LW_AGREE(w, c, "neighbour exchange", false);
   std::vector<size_t> cursor(w->n, 0);
   for (int i = 0; i < n; ++i) {
     if (x[i].nr <= 0) continue;
@@ -145,7 +169,9 @@ int mxg_comm_allgather_dev(mxg_ctx* c, const double* send, size_t n, double* rec
   }
   MXG_HIP(hipStreamSynchronize(s));
   w->gptr[c->rank] = send;
+  MXG_LW_ENTER(w, c, 3, n);
   MXG_LW_BARRIER(w);
+  MXG_LW_AGREE(w, c, "all-gather (device)", true);
   for (int r = 0; r < w->n; ++r)
     MXG_HIP(hipMemcpyAsync(recv + n * r, w->gptr[r], sizeof(double) * n, hipMemcpyDeviceToDevice, s));
   MXG_HIP(hipStreamSynchronize(s));
@@ -168,7 +194,9 @@ extern "C" int mxg_comm_allgather_i64(mxg_ctx* c, int64_t v, int64_t* out) {
   }
   mxg_local_world* w = c->lw;
   w->gcnt[c->rank] = v;
+  MXG_LW_ENTER(w, c, 4, 0);
   MXG_LW_BARRIER(w);
+  MXG_LW_AGREE(w, c, "all-gather (int64)", false);
   for (int r = 0; r < w->n; ++r) out[r] = w->gcnt[r];
   MXG_LW_BARRIER(w);
   return 0;
@@ -201,7 +229,9 @@ extern "C" int mxg_comm_allgatherv(mxg_ctx* c, const void* send, int64_t nbytes,
   }
   mxg_local_world* w = c->lw;
   w->gptr[c->rank] = send;
+  MXG_LW_ENTER(w, c, 5, 0);
   MXG_LW_BARRIER(w);
+  MXG_LW_AGREE(w, c, "all-gather (host bytes)", false);
   int64_t off = 0;
   for (int r = 0; r < w->n; ++r) {
     if (counts[r] > 0) memcpy((char*)recv + off, w->gptr[r], (size_t)counts[r]);
