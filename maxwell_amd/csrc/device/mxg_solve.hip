@@ -164,6 +164,7 @@ struct mxg_mg {
   // Chebyshev smoother (the reference's ML default, `smoother = Chebyshev`): per level the largest eigenvalue of
   // D^-1 A (power iteration at setup); interval [lmax / ratio, boost * lmax]
   bool cheb = false;
+  int deep_mult = 1;                  // smoother steps on levels >= 1 = deep_mult x the level-0 count
   double cheb_ratio = 20.0;
   int coarse_cheb_degree = 0;         // coarsest level: Chebyshev of this degree instead of `coarse` Jacobi sweeps (0 = Jacobi)
   double coarse_cheb_ratio = 100.0;
@@ -310,7 +311,8 @@ int mg_cycle(mxg_mg* mg, int l) {
   if (l == mg->nlevels - 1) return mg->tail ? mg_tail(mg, l) : mg_smooth(mg, l, mg->coarse, true);
   const long long n = mg->A[l]->nrows;
   const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
-  MXG_TRY(mg_smooth(mg, l, mg->pre, true));
+  const int sw = l == 0 ? mg->pre : mg->pre * mg->deep_mult;     // variable V-cycle: more steps on the cheap deeper levels
+  MXG_TRY(mg_smooth(mg, l, sw, true));
   const int rc = mxg_dev_csr_apply_epi(c, mg->A[l], mg->z[l], mg->t[l], 2, mg->r[l]->colptr(0), nullptr, 0.0);   // t = r - A z
   if (rc > 1) return 1;
   if (rc == 1) {
@@ -329,7 +331,7 @@ int mg_cycle(mxg_mg* mg, int l) {
                        (const double*)mg->t[l]->colptr(0), mg->z[l]->colptr(0));
   }
   MXG_HIP(hipGetLastError());
-  return mg_smooth(mg, l, mg->post, false);
+  return mg_smooth(mg, l, sw, false);
 }
 
 }  // namespace
@@ -361,6 +363,7 @@ extern "C" int mxg_mg_create(mxg_ctx* c, int nlevels, mxg_csr* const* A, mxg_csr
     MXG_TRY(mxg_mv_create(c, A[l]->nrows, 1, 0, &t));
     mg->r.push_back(r); mg->z.push_back(z); mg->t.push_back(t);
   }
+  if (const char* e = getenv("MXG_MG_DEEP_MULT")) mg->deep_mult = std::max(1, atoi(e));   // experiments
   if (const char* e = getenv("MXG_MG_CSCALE")) mg->cscale = atof(e);       // experiments (scripts/mg_smoother_sweep.py)
 
   *out = mg;
