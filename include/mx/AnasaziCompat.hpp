@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <complex>
 
@@ -187,14 +189,56 @@ inline bool genEig(int n, const std::vector<std::complex<double> >& A, std::vect
   int hi = n - 1, iter = 0, total = 0;
   std::vector<double> cs(n);
   std::vector<C> sn(n);
+  // norm of the Hessenberg matrix: a subdiagonal entry is also negligible when it is below eps * (a small multiple
+  // of) the norm - two neighbouring diagonal entries that are both (nearly) zero, e.g. a rank-deficient block
+  // column of a block Krylov basis, would otherwise never deflate (EISPACK hqr falls back to the norm the same way)
+  double hnorm = 0.0;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= std::min(j + 1, n - 1); ++i) {
+      if (!std::isfinite(h(i, j).real()) || !std::isfinite(h(i, j).imag())) return false;
+      hnorm = std::max(hnorm, std::abs(h(i, j)));
+    }
   while (hi > 0) {
     int lo = hi;
     while (lo > 0) {
-      const double sc = std::abs(h(lo - 1, lo - 1)) + std::abs(h(lo, lo));
+      const double sc = std::max(std::abs(h(lo - 1, lo - 1)) + std::abs(h(lo, lo)), 1e-6 * hnorm);
       if (std::abs(h(lo, lo - 1)) <= eps * (sc > 0.0 ? sc : 1.0)) { h(lo, lo - 1) = C(0.0); break; }
       --lo;
     }
     if (lo == hi) { --hi; iter = 0; continue; }
+    if (lo == hi - 1) {
+      // 2 x 2 active block: its Schur form directly, from an eigenvector (a nearly defective pair - two equal
+      // diagonal entries over a subdiagonal of 1e-14 - lets the shifted iteration hover at rounding level for ever)
+      const C a = h(lo, lo), b = h(lo, hi), c = h(hi, lo), d = h(hi, hi);
+      const C tr = a + d, det = a * d - b * c;
+      const C disc = std::sqrt(tr * tr * 0.25 - det);
+      const C l1 = tr * 0.5 + disc, l2 = tr * 0.5 - disc;
+      const C mu = std::abs(l1 - d) < std::abs(l2 - d) ? l2 : l1;          // the other one ends up in h(hi, hi)
+      C v0 = b, v1 = mu - a;
+      if (std::norm(mu - d) + std::norm(c) > std::norm(v0) + std::norm(v1)) { v0 = mu - d; v1 = c; }
+      const double vn = std::sqrt(std::norm(v0) + std::norm(v1));
+      if (vn > 0.0) {
+        const C x = v0 / vn, y = v1 / vn;                                   // G = [x -conj(y); y conj(x)], G e1 = v
+        for (int j = lo; j < n; ++j) {                                      // H <- G^H H
+          const C t1 = h(lo, j), t2 = h(hi, j);
+          h(lo, j) = std::conj(x) * t1 + std::conj(y) * t2;
+          h(hi, j) = -y * t1 + x * t2;
+        }
+        for (int i = 0; i <= hi; ++i) {                                     // H <- H G
+          const C t1 = h(i, lo), t2 = h(i, hi);
+          h(i, lo) = t1 * x + t2 * y;
+          h(i, hi) = -t1 * std::conj(y) + t2 * std::conj(x);
+        }
+        for (int i = 0; i < n; ++i) {                                       // Q <- Q G
+          const C t1 = q(i, lo), t2 = q(i, hi);
+          q(i, lo) = t1 * x + t2 * y;
+          q(i, hi) = -t1 * std::conj(y) + t2 * std::conj(x);
+        }
+      }
+      h(hi, lo) = C(0.0);
+      hi -= 2; iter = 0;
+      continue;
+    }
     if (++total > 60 * n + 200) return false;
     ++iter;
     // Wilkinson shift: eigenvalue of the trailing 2x2 closer to h(hi, hi); exceptional shifts on stagnation
@@ -482,7 +526,16 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
       std::vector<double> A((size_t)m * m);
       for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) A[i + (size_t)m * j] = Hat(i, j);
       std::vector<C> w, X;
-      if (!detail::genEig(m, A, w, X)) throw std::runtime_error("BlockKrylovSchur: dense QR iteration did not converge");
+      if (!detail::genEig(m, A, w, X)) {
+        if (const char* dump = std::getenv("MXH_DUMP_DENSE")) {      // diagnostics: the projected matrix, column-major
+          if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(A.data(), sizeof(A[0]), A.size(), f); std::fclose(f); }
+        }
+        size_t bad = 0;
+        for (size_t i = 0; i < A.size(); ++i) bad += std::isfinite(std::abs(A[i])) ? 0 : 1;
+        throw std::runtime_error("BlockKrylovSchur: dense QR iteration did not converge (projected matrix " + std::to_string(m) + " x " +
+                                 std::to_string(m) + ", " + std::to_string(bad) + " non-finite entries, restart " + std::to_string(restarts) +
+                                 (breakdown ? ", after a breakdown of the block recurrence)" : ")"));
+      }
       std::vector<int> order(m);
       std::iota(order.begin(), order.end(), 0);
       sortRitzComplex(w, order);
@@ -681,7 +734,16 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
       std::vector<C> A((size_t)m * m);
       for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) A[i + (size_t)m * j] = Hat(i, j);
       std::vector<C> w, X;
-      if (!detail::genEig(m, A, w, X)) throw std::runtime_error("BlockKrylovSchur: dense QR iteration did not converge");
+      if (!detail::genEig(m, A, w, X)) {
+        if (const char* dump = std::getenv("MXH_DUMP_DENSE")) {      // diagnostics: the projected matrix, column-major
+          if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(A.data(), sizeof(A[0]), A.size(), f); std::fclose(f); }
+        }
+        size_t bad = 0;
+        for (size_t i = 0; i < A.size(); ++i) bad += std::isfinite(std::abs(A[i])) ? 0 : 1;
+        throw std::runtime_error("BlockKrylovSchur: dense QR iteration did not converge (projected matrix " + std::to_string(m) + " x " +
+                                 std::to_string(m) + ", " + std::to_string(bad) + " non-finite entries, restart " + std::to_string(restarts) +
+                                 (breakdown ? ", after a breakdown of the block recurrence)" : ")"));
+      }
       std::vector<int> order(m);
       std::iota(order.begin(), order.end(), 0);
       sortRitzComplex(w, order);

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_xwin(
 template <int SBLK_, int NNZ_BLK_>
 struct RgCfg {
   static constexpr int SBLK = SBLK_, NNZ_BLK = NNZ_BLK_;
-  static constexpr int NNZ_CAP = NNZ_BLK_ - 1;
+  static constexpr int NNZ_CAP = NNZ_BLK_ - 4;     // the LDS image starts at a 16-byte aligned entry: <= 3 entries of slack
   static constexpr int ROWS_CAP = SBLK_;          // one row per thread
   static constexpr int EPT = NNZ_BLK_ / SBLK_;
 };
@@ -586,6 +586,151 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
 
 
 // ------------------------------------------------------------------------------------------
+// Persistent, double-buffered row-gather kernel ("rgp"): the same arithmetic as k_spmv_rowgather, but a
+// workgroup walks a strided sequence of row blocks and the NEXT block's values / columns / row offsets are
+// already on their way into the other half of LDS - by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no
+// ds_write) - while the current block gathers x.  One block per launch slot paid four dependent round trips
+// (descriptor -> stream -> gather -> store) with its 24 KiB of LDS idle for three of them; here the descriptor
+// is two iterations ahead (scalar loads), the stream one iteration ahead, and a CU always has 3 x 24 KiB of
+// matrix stream in flight.  Workgroups of one XCD take interleaved blocks of that XCD's contiguous eighth, so
+// they advance through x together and the 4 MiB L2 sees the same window as before.
+// LDS image of a block = the global arrays from a 16-byte aligned start: entry q of the block's CSR range sits
+// at sval[q - (base & ~1)] and scol[q - (base & ~3)]; row offsets come from a copy laid out 528 B per block.
+// ------------------------------------------------------------------------------------------
+constexpr int RGP_NNZ_CAP = RgCfgA::NNZ_CAP;   // 2044: + <= 3 entries of alignment slack stays inside 2048 slots
+constexpr int RGP_ROFF_STRIDE = 264;       // ushorts per block in roff16[] (257 offsets, padded to 16 B)
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA piece: every active lane moves 16 bytes from its own global address to LDS at base + 16 * lane
+// (base wave-uniform, in M0).  Written as inline asm on purpose: with the builtin, hipcc (ROCm 7.2) puts an
+// s_waitcnt vmcnt(0) in front of every later LDS read, which would serialise the next block's stream with this
+// block's gathers.  The asm is invisible to the compiler's counters, so the kernel waits for it explicitly
+// (s_waitcnt vmcnt(0) + barrier before the first read of a staged block).  NT: non-temporal (streamed once).
+template <int NT>
+__device__ inline void lds_dma16(const void* g, void* l) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)l);
+  unsigned keep;
+  if (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+__device__ inline void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// the fields of a BlkDesc the kernel needs, as scalars (copying the 32-byte struct drags its padding through a
+// vector load whose wait would drain the LDS-DMA queue)
+struct RgpBlk { long long base; int r0, nr, nnzb; };
+__device__ inline RgpBlk rgp_desc(const BlkDesc* __restrict__ desc, long long b) {
+  RgpBlk d;
+  d.base = desc[b].base; d.r0 = desc[b].r0; d.nr = desc[b].nr; d.nnzb = desc[b].nnzb;
+  return d;
+}
+
+template <int AUX>
+__device__ inline void rgp_issue(const RgpBlk& d, const int* __restrict__ colidx, const double* __restrict__ vals,
+                                 const unsigned short* __restrict__ roff16, long long b, double* sv, int* sc,
+                                 unsigned short* sr) {
+  if (d.nnzb > RGP_NNZ_CAP) return;        // one over-long row: read in place by the whole workgroup
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long end = d.base + d.nnzb;
+  const long long lo = d.base & ~1LL, lo4 = d.base & ~3LL;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {            // values: 16 pieces of 1 KiB, four per wave
+    const int piece = wave + 4 * p;
+    const long long idx = lo + 128 * piece + 2 * lane;
+    if (idx < end) lds_dma16<AUX>(vals + idx, sv + 128 * piece);
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {            // columns: 8 pieces, two per wave
+    const int piece = wave + 4 * p;
+    const long long idx = lo4 + 256 * piece + 4 * lane;
+    if (idx < end) lds_dma16<AUX>(colidx + idx, sc + 256 * piece);
+  }
+  if (wave == 0 && 8 * lane <= d.nr) lds_dma16<0>(roff16 + b * RGP_ROFF_STRIDE + 8 * lane, sr);
+}
+
+// x, y: first column and leading dimension (contiguous column ranges; the host splits other views into ranges)
+template <int CH, int AUX>
+__global__ __launch_bounds__(256) void k_spmv_rgp(
+    const BlkDesc* __restrict__ desc, long long nblocks, const int* __restrict__ colidx,
+    const double* __restrict__ vals, const unsigned short* __restrict__ roff16,
+    const double* __restrict__ x0, long long ldx, double* __restrict__ y0, long long ldy, int k) {
+  __shared__ __attribute__((aligned(16))) double sval[2][2048];
+  __shared__ __attribute__((aligned(16))) int scol[2][2048];
+  __shared__ __attribute__((aligned(16))) unsigned short sroff[2][RGP_ROFF_STRIDE + 8];
+  const long long W = gridDim.x / MXG_NUM_XCD;                 // workgroups per XCD (grid is a multiple of 8)
+  const long long per = (nblocks + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+  const long long xcd = blockIdx.x % MXG_NUM_XCD;
+  long long b = xcd * per + blockIdx.x / MXG_NUM_XCD;
+  const long long last = min((xcd + 1) * per, nblocks);
+  if (b >= last) return;
+  const int t = threadIdx.x;
+  RgpBlk d = rgp_desc(desc, b), dn = d;
+  rgp_issue<AUX>(d, colidx, vals, roff16, b, sval[0], scol[0], sroff[0]);
+  bool has_next = b + W < last;
+  if (has_next) dn = rgp_desc(desc, b + W);
+  for (int it = 0; b < last; b += W, ++it) {
+    const int s = it & 1;
+    lds_dma_wait_all();
+    __syncthreads();       // block b has landed (every wave waited for its own pieces), nobody reads the other half any more
+    RgpBlk dnn = dn;
+    const bool has_nn = b + 2 * W < last;
+    if (has_next) {
+      rgp_issue<AUX>(dn, colidx, vals, roff16, b + W, sval[s ^ 1], scol[s ^ 1], sroff[s ^ 1]);
+      if (has_nn) dnn = rgp_desc(desc, b + 2 * W);
+    }
+    if (d.nnzb > RGP_NNZ_CAP) {
+      for (int j = 0; j < k; ++j) {
+        const double* x = x0 + j * ldx;
+        double sr = 0.0;
+        for (long long q = d.base + t; q < d.base + d.nnzb; q += 256) sr += vals[q] * x[colidx[q]];
+        __syncthreads();
+        sval[s][t] = sr;
+        __syncthreads();
+        if (t == 0) {
+          double tr = 0.0;
+          for (int q = 0; q < 256; ++q) tr += sval[s][q];
+          y0[j * ldy + d.r0] = tr;
+        }
+      }
+    } else {
+      const double* __restrict__ sv = sval[s] + (int)(d.base & 1);
+      const int* __restrict__ sc = scol[s] + (int)(d.base & 3);
+      int o0 = 0, o1 = 0;
+      if (t < d.nr) { o0 = sroff[s][t]; o1 = sroff[s][t + 1]; }
+      for (int j = 0; j < k; ++j) {
+        const double* __restrict__ x = x0 + j * ldx;
+        double sum = 0.0;
+        for (int q0 = o0; q0 < o1; q0 += CH) {
+          // branch-free chunk: indices clamped into the row, so the CH column / value reads and the CH gathers are
+          // issued back to back; entries past the row's end are computed and discarded
+          double v[CH], xv[CH];
+          int cc[CH];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const int q = min(q0 + i, o1 - 1);
+            cc[i] = sc[q];
+            v[i] = sv[q];
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i) xv[i] = x[cc[i]];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const double s2 = sum + v[i] * xv[i];
+            sum = q0 + i < o1 ? s2 : sum;
+          }
+        }
+        if (t < d.nr) __builtin_nontemporal_store(sum, y0 + j * ldy + d.r0 + t);
+      }
+    }
+    d = dn; dn = dnn; has_next = has_nn;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Compressed-stream variant of the row-gather kernel (opt-in: mxg_csr_compress).
 // The operators of the Yee lattice are structured: inside a block of 256 consecutive rows the
 // column indices fall into a handful of narrow bands (one per stencil leg) and, away from cut
@@ -603,10 +748,17 @@ struct CsDesc {
   long long soff;   // byte offset of the block's packed stream (16-byte aligned); -1: plain CSR block
   int r0, nrnv, nnzb, rb;   // nrnv = rows (<= 256) | distinct values << 16; rb = position of the block's row offsets in roff[]
   __host__ __device__ inline int nr() const { return nrnv & 0xffff; }
-  __host__ __device__ inline int nval() const { return nrnv >> 16; }
+  __host__ __device__ inline int nval() const { return (nrnv >> 16) & 0x1ff; }
+  // the block's record holds only its row offsets (more bands / distinct values / bytes than the packed form takes):
+  // columns and values come from the CSR arrays
+  __host__ __device__ inline bool roff_only() const { return (nrnv >> 30) & 1; }
 };
+constexpr int CS_ROFF_ONLY = 1 << 30;
 static_assert(sizeof(CsDesc) == 32, "descriptor layout");
 constexpr int CS_SEGS = 16, CS_OFFBITS = 12, CS_MAXVAL = 256;
+// every record starts with a 32-byte header {r0, nrnv (as in CsDesc), nnzb, 0, base, 0}: the persistent kernel's
+// consumer waves take a block's shape from LDS and never wait for a global descriptor
+constexpr int CS_HDR = 32;
 
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
@@ -680,9 +832,9 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     }
     return;
   }
-  const bool packed = d.soff >= 0;
+  const bool packed = d.soff >= 0 && !d.roff_only();
   if (packed) {
-    const unsigned char* sp = stream + d.soff;
+    const unsigned char* sp = stream + d.soff + CS_HDR;
     if (t < CS_SEGS) sseg[t] = nt_load(reinterpret_cast<const int*>(sp) + t);
     const double* vt = reinterpret_cast<const double*>(sp + CS_SEGS * 4);
 #pragma unroll 1
@@ -764,6 +916,183 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// Persistent compressed-stream kernel ("csp"): a dedicated LOADER wave keeps the packed records of the next D - 1
+// row blocks in flight by LDS-DMA into a ring of D slots while four CONSUMER waves (one row per thread) decode
+// and gather the current one.  k_spmv_cs has one block per workgroup and three dependent round trips per block
+// (descriptor -> record -> gathers); at 16 waves per CU that left ~0.8 GB moving at 3.8 TB/s.  Here
+//   * a block's record (band origins, value table, codes, value ids AND its row offsets) is one contiguous,
+//     16-byte aligned run of <= 8 KiB = eight 1 KiB DMA pieces, always eight (lanes past the end re-read the
+//     record's first bytes), so the loader's vmcnt arithmetic is static: after issuing block i + D - 1 it waits
+//     s_waitcnt vmcnt(8 (D - 2)), i.e. for block i + 1, and never drains the queue;
+//   * vmcnt is per wave: the consumers' gathers and stores do not touch the loader's counter, and the DMA is inline
+//     asm, so the compiler puts no wait in front of the consumers' LDS reads;
+//   * one raw s_barrier per block hands slot i to the consumers and slot i - 1 back to the loader;
+//   * 24 KiB of LDS per workgroup at D = 3: six workgroups (24 consumer waves, 12 records in flight) per CU.
+// Same decode, same products, same summation order as k_spmv_cs: bit-identical results.
+// ------------------------------------------------------------------------------------------
+constexpr int CSP_SLOT = 8192;                       // bytes per ring slot = 8 pieces
+constexpr int CSP_THREADS = 320;                     // 4 consumer waves + 1 loader wave
+
+__host__ __device__ inline int cs_roff_bytes(int nr) { return ((nr + 1 + 7) >> 3) * 16; }
+// bytes of a block's record; packed: [header][16 band origins][value table][codes][value ids][row offsets]
+__host__ __device__ inline int cs_record_bytes(int nnzb, int nval, int nr, bool roff_only) {
+  if (roff_only) return CS_HDR + CS_SEGS * 4 + cs_roff_bytes(nr);
+  return CS_HDR + CS_SEGS * 4 + ((nval + 1) & ~1) * 8 + ((nnzb + 7) >> 3) * 16 + ((nnzb + 15) >> 4) * 16 + cs_roff_bytes(nr);
+}
+
+// workgroup barrier for LDS hand-offs without the vmcnt(0) a __syncthreads() carries: the wave's own LDS operations
+// are complete, the "memory" clobber keeps the compiler from moving LDS accesses across it
+__device__ inline void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N> __device__ inline void csp_wait_pieces();
+template <> __device__ inline void csp_wait_pieces<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ inline void csp_wait_pieces<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <> __device__ inline void csp_wait_pieces<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+template <> __device__ inline void csp_wait_pieces<24>() { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+
+template <int CH, bool DOT, int EPI, int D>
+__global__ __launch_bounds__(CSP_THREADS) void k_spmv_csp(
+    const CsDesc* __restrict__ desc, long long nblocks, const unsigned char* __restrict__ stream,
+    const int* __restrict__ colidx, const double* __restrict__ vals,
+    const double* __restrict__ x, double* __restrict__ y,
+    const double* __restrict__ xdot, double* __restrict__ partial,
+    const double* __restrict__ rhs, const double* __restrict__ diag, double omega, double beta) {
+  __shared__ __attribute__((aligned(16))) unsigned char ring[D][CSP_SLOT];
+  __shared__ double sred[2][4];
+  const long long W = gridDim.x / MXG_NUM_XCD;
+  const long long per = (nblocks + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
+  const long long xcd = blockIdx.x % MXG_NUM_XCD;
+  const long long first = xcd * per + blockIdx.x / MXG_NUM_XCD;
+  const long long last = min((xcd + 1) * per, nblocks);
+  if (first >= last) return;
+  const int t = threadIdx.x;
+  if (t >= 256) {
+    // ------------------------------------------------------------------ loader wave
+    const int lane = t & 63;
+    // where block bb's record is and how long: (offset, bytes); (0, 0) past the end -> eight dummy pieces of the
+    // stream's first bytes keep the vmcnt arithmetic static
+    auto where = [&](long long bb, long long& soff, int& bytes) {
+      soff = 0; bytes = 0;
+      if (bb < last) {
+        soff = desc[bb].soff;
+        const int nnzb = desc[bb].nnzb, nrnv = desc[bb].nrnv;
+        bytes = nnzb > RgCfgA::NNZ_CAP ? CS_HDR : cs_record_bytes(nnzb, (nrnv >> 16) & 0x1ff, nrnv & 0xffff, (nrnv >> 30) & 1);
+      }
+    };
+    auto issue = [&](long long soff, int bytes, int slot) {
+      const unsigned char* rec = stream + soff;
+#pragma unroll
+      for (int p = 0; p < CSP_SLOT / 1024; ++p) {          // eight pieces, all 64 lanes always active
+        const int off = 1024 * p + 16 * lane;
+        lds_dma16<1>(rec + (off < bytes ? off : 0), ring[slot] + 1024 * p);
+      }
+    };
+    long long so, so_next;
+    int by, by_next;
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) { where(first + j * W, so, by); issue(so, by, j); }
+    where(first + (D - 1) * W, so_next, by_next);
+    int it = 0;
+    for (long long b = first; b < last; b += W, ++it) {
+      csp_wait_pieces<8 * (D - 2)>();                       // block `it` has landed, D - 2 younger ones stay in flight
+      asm volatile("s_barrier" ::: "memory");               // consumers: slot it % D is yours, slot (it - 1) % D is mine
+      so = so_next; by = by_next;
+      where(b + D * W, so_next, by_next);                 // descriptor of the block after next: a whole iteration ahead
+      issue(so, by, (it + D - 1) % D);
+    }
+    csp_wait_pieces<0>();
+    asm volatile("s_barrier" ::: "memory");
+    return;
+  }
+  // -------------------------------------------------------------------- consumer waves: one row per thread
+  int it = 0;
+  long long bprev = -1, rprev = 0;
+  bool lprev = false;
+  for (long long b = first; b < last; b += W, ++it) {
+    wg_barrier_lds();                                     // the record of block b is in ring[it % D]
+    if (t == 0 && bprev >= 0) {                           // finish the previous block's cross-wave sums
+      const double* sp = sred[(it - 1) & 1];
+      const double tot = ((sp[0] + sp[1]) + sp[2]) + sp[3];
+      if (lprev) { y[rprev] = cs_epilogue<EPI>(tot, rprev, x, rhs, diag, omega, beta, y); if (DOT) partial[bprev] = tot * xdot[rprev]; }
+      else if (DOT) partial[bprev] = tot;
+    }
+    const unsigned char* rec = ring[it % D];
+    const int* hdr = reinterpret_cast<const int*>(rec);
+    const int r0 = hdr[0], nrnv = hdr[1], nnzb = hdr[2];
+    const int nr = nrnv & 0xffff, nvpad = (((nrnv >> 16) & 0x1ff) + 1) & ~1;
+    const bool roff_only = (nrnv >> 30) & 1;
+    const bool longrow = nnzb > RgCfgA::NNZ_CAP;
+    double part = 0.0;
+    if (longrow) {
+      // one over-long row: the four waves share it, wave sums are combined in wave order after the next barrier
+      const long long base = reinterpret_cast<const long long*>(rec)[2];
+#pragma unroll 1
+      for (long long q = base + t; q < base + nnzb; q += 256) part += vals[q] * x[colidx[q]];
+    } else if (t < nr) {
+      double sum = 0.0;
+      if (!roff_only) {
+        const int* sseg = reinterpret_cast<const int*>(rec + CS_HDR);
+        const double* svtab = reinterpret_cast<const double*>(rec + CS_HDR + CS_SEGS * 4);
+        const unsigned short* scode = reinterpret_cast<const unsigned short*>(rec + CS_HDR + CS_SEGS * 4 + nvpad * 8);
+        const unsigned char* svid = rec + CS_HDR + CS_SEGS * 4 + nvpad * 8 + ((nnzb + 7) >> 3) * 16;
+        const unsigned short* sroff = reinterpret_cast<const unsigned short*>(svid + ((nnzb + 15) >> 4) * 16);
+        const int o0 = sroff[t], o1 = sroff[t + 1];
+        // Branch-free head: LDS indices are clamped into the row (an empty row reads slot bytes it never uses and
+        // gathers x[0]), so the compiler batches the CH code reads, then the band origins, value ids and table reads,
+        // and every gather of the row is in flight before the first product.
+        const int qlast = o1 > o0 ? o1 - 1 : o0;
+        double v[CH], xv[CH];
+        unsigned code[CH];
+        int vid[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int q = min(o0 + i, qlast);
+          code[i] = scode[q];
+          vid[i] = svid[q];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int cc = sseg[code[i] >> CS_OFFBITS] + (int)(code[i] & ((1u << CS_OFFBITS) - 1u));
+          xv[i] = x[o0 + i < o1 ? cc : 0];
+          v[i] = svtab[vid[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const double s2 = sum + v[i] * xv[i];
+          sum = o0 + i < o1 ? s2 : sum;
+        }
+#pragma unroll 1
+        for (int q = o0 + CH; q < o1; ++q) {              // longer rows: the tail, in storage order
+          const unsigned code1 = scode[q];
+          sum += svtab[svid[q]] * x[sseg[code1 >> CS_OFFBITS] + (int)(code1 & ((1u << CS_OFFBITS) - 1u))];
+        }
+      } else {
+        const long long base = reinterpret_cast<const long long*>(rec)[2];
+        const unsigned short* sroff = reinterpret_cast<const unsigned short*>(rec + CS_HDR + CS_SEGS * 4);
+        const int o0 = sroff[t], o1 = sroff[t + 1];
+#pragma unroll 1
+        for (long long q = base + o0; q < base + o1; ++q) sum += vals[q] * x[colidx[q]];
+      }
+      __builtin_nontemporal_store(cs_epilogue<EPI>(sum, (long long)r0 + t, x, rhs, diag, omega, beta, y), y + r0 + t);
+      if (DOT) part = sum * xdot[r0 + t];
+    }
+    if (DOT || longrow) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+      if ((t & 63) == 0) sred[it & 1][t >> 6] = part;
+    }
+    bprev = (DOT || longrow) ? b : -1; rprev = r0; lprev = longrow;
+  }
+  wg_barrier_lds();
+  if (t == 0 && bprev >= 0) {
+    const double* sp = sred[(it - 1) & 1];
+    const double tot = ((sp[0] + sp[1]) + sp[2]) + sp[3];
+    if (lprev) { y[rprev] = cs_epilogue<EPI>(tot, rprev, x, rhs, diag, omega, beta, y); if (DOT) partial[bprev] = tot * xdot[rprev]; }
+    else if (DOT) partial[bprev] = tot;
+  }
+}
+
 
 // out[0] = sum of partial[0..n) in index order (single workgroup, fixed tree: reproducible)
 __global__ void k_sum_partials(const double* __restrict__ partial, long long n, double* __restrict__ out) {
@@ -883,13 +1212,13 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
   std::vector<int32_t> blk = build_row_blocks(rowptr, nrows, CfgDefault::NNZ_CAP, CfgDefault::ROWS_BLK);
   a->nblocks = (int64_t)blk.size() - 1;
 
-  // +2 entries of slack: the real kernel loads aligned pairs and may touch one element past nnz
+  // +8 entries of slack: the kernels load aligned pairs / 16-byte pieces and may touch a few elements past nnz
   MXG_HIP(hipMalloc(&a->d_rowptr, sizeof(int64_t) * (nrows + 1)));
-  MXG_HIP(hipMalloc(&a->d_colidx, sizeof(int32_t) * (nnz + 2)));
-  MXG_HIP(hipMalloc(&a->d_vals, sizeof(double) * (nnz + 2) * w));
+  MXG_HIP(hipMalloc(&a->d_colidx, sizeof(int32_t) * (nnz + 8)));
+  MXG_HIP(hipMalloc(&a->d_vals, sizeof(double) * (nnz + 8) * w));
   MXG_HIP(hipMalloc(&a->d_rowblk, sizeof(int32_t) * blk.size()));
-  MXG_HIP(hipMemsetAsync(a->d_colidx, 0, sizeof(int32_t) * (nnz + 2), c->stream));
-  MXG_HIP(hipMemsetAsync(a->d_vals, 0, sizeof(double) * (nnz + 2) * w, c->stream));
+  MXG_HIP(hipMemsetAsync(a->d_colidx, 0, sizeof(int32_t) * (nnz + 8), c->stream));
+  MXG_HIP(hipMemsetAsync(a->d_vals, 0, sizeof(double) * (nnz + 8) * w, c->stream));
   MXG_HIP(hipMemcpyAsync(a->d_rowptr, rowptr, sizeof(int64_t) * (nrows + 1), hipMemcpyHostToDevice,
                          c->stream));
   if (nnz > 0) {
@@ -952,6 +1281,7 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
   if (a->d_dotpartial) hipFree(a->d_dotpartial);
   if (a->d_roff) hipFree(a->d_roff);
+  if (a->d_roff16) hipFree(a->d_roff16);
   if (a->d_csdesc) hipFree(a->d_csdesc);
   if (a->d_csstream) hipFree(a->d_csstream);
   if (a->d_xwdesc) hipFree(a->d_xwdesc);
@@ -1098,7 +1428,7 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
   }
   int cap = geo == 0 ? PipeCfgA::NNZ_CAP : PipeCfgB::NNZ_CAP;
   int rows_cap = 2 * (geo == 0 ? PipeCfgA::SBLK : PipeCfgB::SBLK);
-  if (geo == 10) { cap = RgCfgA::NNZ_CAP; rows_cap = RgCfgA::ROWS_CAP; }
+  if (geo == 10) { cap = RGP_NNZ_CAP; rows_cap = RgCfgA::ROWS_CAP; }   // 2044: the persistent kernel's 16-byte aligned LDS image
   if (geo == 11) { cap = RgCfgB::NNZ_CAP; rows_cap = RgCfgB::ROWS_CAP; }
   std::vector<int32_t> blk = build_row_blocks(host_rowptr, a->nrows, cap, rows_cap);
   std::vector<BlkDesc> desc(blk.size() - 1);
@@ -1147,6 +1477,20 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
   if (!desc.empty())
     MXG_HIP(hipMemcpyAsync(a->d_blkdesc, desc.data(), sizeof(BlkDesc) * desc.size(),
                            hipMemcpyHostToDevice, c->stream));
+  if (a->d_roff16) { hipFree(a->d_roff16); a->d_roff16 = nullptr; }
+  if (geo == 10) {
+    // persistent kernel: the same offsets, RGP_ROFF_STRIDE ushorts per block in descriptor order, so that a block's
+    // offsets are one 16-byte aligned LDS-DMA piece
+    std::vector<unsigned short> r16(desc.size() * (size_t)RGP_ROFF_STRIDE + 8, 0);
+#pragma omp parallel for schedule(static)
+    for (long long b = 0; b < (long long)desc.size(); ++b) {
+      const BlkDesc& d = desc[(size_t)b];
+      if (d.nnzb > cap) continue;
+      for (int r = 0; r <= d.nr; ++r) r16[(size_t)b * RGP_ROFF_STRIDE + r] = (unsigned short)(host_rowptr[d.r0 + r] - d.base);
+    }
+    MXG_HIP(hipMalloc(&a->d_roff16, sizeof(unsigned short) * r16.size()));
+    MXG_HIP(hipMemcpyAsync(a->d_roff16, r16.data(), sizeof(unsigned short) * r16.size(), hipMemcpyHostToDevice, c->stream));
+  }
   MXG_HIP(hipStreamSynchronize(c->stream));
   a->npipe = (int64_t)desc.size();
   a->pipe_geo = geo;
@@ -1172,7 +1516,30 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
       d.soff = -1;
       d.rb = d.r0 + (int)b;
       desc[b] = d;
-      if (d.nnzb > RgCfgA::NNZ_CAP || d.nnzb == 0) continue;
+      const int nr = d.nrnv;
+      std::vector<unsigned char>& pk = packs[b];
+      auto header = [&]() {                                 // after desc[b].nrnv has its flags
+        int32_t h[8] = {d.r0, desc[b].nrnv, d.nnzb, 0, 0, 0, 0, 0};
+        std::memcpy(h + 4, &d.base, sizeof d.base);
+        std::memcpy(pk.data(), h, sizeof h);
+      };
+      if (d.nnzb > RgCfgA::NNZ_CAP) {                       // one over-long row: header only, the row is read in place
+        pk.assign(CS_HDR, 0);
+        desc[b].soff = 0;
+        header();
+        continue;
+      }
+      // every other block has a record that ends with its 16-bit row offsets; the packed form in front of them when
+      // the block's columns fit 16 bands of 2^12, its distinct values a table of 256 and the whole record 8 KiB
+      auto roff_only = [&]() {
+        pk.assign((size_t)cs_record_bytes(d.nnzb, 0, nr, true), 0);
+        unsigned short* ro = reinterpret_cast<unsigned short*>(pk.data() + CS_HDR + CS_SEGS * 4);
+        for (int r = 0; r <= nr; ++r) ro[r] = (unsigned short)(rp[d.r0 + r] - d.base);
+        desc[b].nrnv |= CS_ROFF_ONLY;
+        desc[b].soff = 0;   // final offset assigned below
+        header();
+      };
+      if (d.nnzb == 0) { roff_only(); continue; }
       // column bands: greedy cover of the sorted distinct columns with windows of 2^12
       u.assign(ci + d.base, ci + d.base + d.nnzb);
       std::sort(u.begin(), u.end());
@@ -1186,23 +1553,25 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
         const int64_t lim = (int64_t)u[i] + (1 << CS_OFFBITS);
         while (i < u.size() && u[i] < lim) ++i;
       }
-      if (!ok) continue;
+      if (!ok) { roff_only(); continue; }
       // distinct values by bit pattern
       w.resize((size_t)d.nnzb);
       std::memcpy(w.data(), va + d.base, sizeof(double) * (size_t)d.nnzb);
       std::sort(w.begin(), w.end());
       w.erase(std::unique(w.begin(), w.end()), w.end());
-      if (w.size() > (size_t)CS_MAXVAL) continue;
+      if (w.size() > (size_t)CS_MAXVAL) { roff_only(); continue; }
       const int nval = (int)w.size(), nvpad = (nval + 1) & ~1;
       const size_t ncode16 = ((size_t)d.nnzb + 7) >> 3, nid16 = ((size_t)d.nnzb + 15) >> 4;
-      std::vector<unsigned char>& pk = packs[b];
-      pk.assign(CS_SEGS * 4 + (size_t)nvpad * 8 + ncode16 * 16 + nid16 * 16, 0);
+      const size_t nbytes = (size_t)cs_record_bytes(d.nnzb, nval, nr, false);
+      if (nbytes > (size_t)CSP_SLOT) { roff_only(); continue; }
+      pk.assign(nbytes, 0);
       int32_t segpad[CS_SEGS];
       for (int i = 0; i < CS_SEGS; ++i) segpad[i] = i < nseg ? seg[i] : 0;
-      std::memcpy(pk.data(), segpad, sizeof segpad);
-      std::memcpy(pk.data() + CS_SEGS * 4, w.data(), sizeof(uint64_t) * (size_t)nval);
-      unsigned short* code = reinterpret_cast<unsigned short*>(pk.data() + CS_SEGS * 4 + (size_t)nvpad * 8);
-      unsigned char* vid = pk.data() + CS_SEGS * 4 + (size_t)nvpad * 8 + ncode16 * 16;
+      std::memcpy(pk.data() + CS_HDR, segpad, sizeof segpad);
+      std::memcpy(pk.data() + CS_HDR + CS_SEGS * 4, w.data(), sizeof(uint64_t) * (size_t)nval);
+      unsigned short* code = reinterpret_cast<unsigned short*>(pk.data() + CS_HDR + CS_SEGS * 4 + (size_t)nvpad * 8);
+      unsigned char* vid = pk.data() + CS_HDR + CS_SEGS * 4 + (size_t)nvpad * 8 + ncode16 * 16;
+      unsigned short* ro = reinterpret_cast<unsigned short*>(vid + nid16 * 16);
       for (int q = 0; q < d.nnzb; ++q) {
         const int32_t col = ci[d.base + q];
         const int sidx = (int)(std::upper_bound(seg, seg + nseg, col) - seg) - 1;
@@ -1211,8 +1580,10 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
         std::memcpy(&bits, va + d.base + q, sizeof bits);
         vid[q] = (unsigned char)(std::lower_bound(w.begin(), w.end(), bits) - w.begin());
       }
+      for (int r = 0; r <= nr; ++r) ro[r] = (unsigned short)(rp[d.r0 + r] - d.base);
       desc[b].nrnv |= nval << 16;
       desc[b].soff = 0;   // final offset assigned below
+      header();
     }
   };
   unsigned nthreads = std::thread::hardware_concurrency();
@@ -1225,11 +1596,11 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
   for (auto& th : pool) th.join();
   size_t total = 0, nfall = 0;
   for (size_t b = 0; b < nb; ++b) {
-    if (desc[b].soff < 0) { if (desc[b].nnzb > 0) ++nfall; continue; }
+    if (desc[b].nnzb > RgCfgA::NNZ_CAP || (desc[b].roff_only() && desc[b].nnzb > 0)) ++nfall;
     desc[b].soff = (long long)total;
     total += packs[b].size();
   }
-  std::vector<unsigned char> stream(total + 16, 0);
+  std::vector<unsigned char> stream(total + 64, 0);      // (a dummy DMA piece of the loader reads bytes 0..16)
   for (size_t b = 0; b < nb; ++b)
     if (desc[b].soff >= 0) std::memcpy(stream.data() + desc[b].soff, packs[b].data(), packs[b].size());
   a->ncs_interior = (int64_t)nb;
@@ -1281,7 +1652,9 @@ extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const in
     }
     MXG_TRY(build_cs(a, rowptr, colidx, vals));
   }
+  // 0x8000000: the persistent kernel with a loader wave (k_spmv_csp); MXG_CSP=0 keeps one block per workgroup
   a->kernel = MXG_KERNEL_DEFAULT | 0x1000000;
+  { const char* e = getenv("MXG_CSP"); if (!e || atoi(e) != 0) a->kernel |= 0x8000000; }
   if (nblocks) *nblocks = a->ncs;
   if (nfallback) *nfallback = a->cs_fallback;
   if (stream_bytes) *stream_bytes = a->cs_bytes;
@@ -1432,6 +1805,27 @@ static int launch_rowgather_halo(mxg_ctx* c, mxg_csr* a, const MvDesc& X, const 
   return 0;
 }
 
+// persistent compressed-stream kernel (no halo): D = 3 ring, six 320-thread workgroups per CU
+constexpr int CSP_DEPTH = 3;
+static inline bool csp_on(const mxg_csr* a) { return (a->kernel & 0x8000000) != 0; }
+template <bool DOT, int EPI>
+static void launch_csp(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const double* xdot, double* partial,
+                       const double* rhs, const double* diag, double omega, double beta) {
+  int wgs = 6;
+  if (const char* e = getenv("MXG_CSP_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 8) wgs = v; }
+  const unsigned grid = (unsigned)std::max(MXG_NUM_XCD, (c->num_cu * wgs / MXG_NUM_XCD) * MXG_NUM_XCD);
+  int depth = CSP_DEPTH;
+  if (const char* e = getenv("MXG_CSP_DEPTH")) depth = atoi(e);
+  if (depth == 4 && !DOT && EPI == 0)        // tuning variant (plain product only)
+    hipLaunchKernelGGL((k_spmv_csp<7, false, 0, 4>), dim3(grid), dim3(CSP_THREADS), 0, c->stream,
+                       (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
+                       (const int*)a->d_colidx, (const double*)a->d_vals, x, y, xdot, partial, rhs, diag, omega, beta);
+  else
+  hipLaunchKernelGGL((k_spmv_csp<7, DOT, EPI, CSP_DEPTH>), dim3(grid), dim3(CSP_THREADS), 0, c->stream,
+                     (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
+                     (const int*)a->d_colidx, (const double*)a->d_vals, x, y, xdot, partial, rhs, diag, omega, beta);
+}
+
 // compressed-stream kernel on a row-partitioned matrix (real, one column): interior blocks, wait for the halo,
 // boundary blocks with ghost reads.  halo_start(c, a, x) must have been called.
 template <bool DOT, int EPI>
@@ -1511,11 +1905,33 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
     const long long per = (a->ncs + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
     for (int j = 0; j < X.k; ++j)
+      if (csp_on(a))
+        launch_csp<false, 0>(c, a, (const double*)X.col(j), Y.col(j), nullptr, nullptr, nullptr, nullptr, 0.0, 0.0);
+      else
       hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
                          (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
                          (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(j), Y.col(j),
                          (const double*)nullptr, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0,
                          (const double*)nullptr, 0LL, 0.0);
+  } else if ((a->kernel & 0x2000000) && !a->is_complex && a->npipe > 0 && a->pipe_geo == 10 && a->d_roff16) {
+    // persistent double-buffered row-gather kernel: 3 workgroups (2 x 24.5 KiB of LDS each) per CU
+    const unsigned grid = (unsigned)std::max(MXG_NUM_XCD, (c->num_cu * 3 / MXG_NUM_XCD) * MXG_NUM_XCD);
+    const int ch = (a->kernel >> 20) & 0xF;
+#define MXG_RGP(CHV, AUX)                                                                            \
+    hipLaunchKernelGGL((k_spmv_rgp<CHV, AUX>), dim3(grid), dim3(256), 0, c->stream, (const BlkDesc*)a->d_blkdesc, \
+                       (long long)a->npipe, (const int*)a->d_colidx, (const double*)a->d_vals,          \
+                       (const unsigned short*)a->d_roff16, (const double*)X.base + X.ld * xc0, (long long)X.ld, \
+                       Y.base + Y.ld * yc0, (long long)Y.ld, kk)
+    // contiguous column ranges of both views (one launch for a plain block of vectors)
+    for (int j0 = 0; j0 < X.k;) {
+      int kk = 1;
+      while (j0 + kk < X.k && x->hcols[j0 + kk] == x->hcols[j0] + kk && y->hcols[j0 + kk] == y->hcols[j0] + kk) ++kk;
+      const long long xc0 = X.base == x->base ? x->hcols[j0] : j0, yc0 = y->hcols[j0];
+      if (a->kernel & 0x4000000) { if (ch == 4) MXG_RGP(4, 0); else if (ch == 7) MXG_RGP(7, 0); else MXG_RGP(8, 0); }
+      else { if (ch == 4) MXG_RGP(4, 2); else if (ch == 7) MXG_RGP(7, 2); else MXG_RGP(8, 2); }
+      j0 += kk;
+    }
+#undef MXG_RGP
   } else if ((a->kernel & 0x30000) && !a->is_complex && a->npipe > 0) {
     const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
@@ -1615,6 +2031,16 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
                      (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,        \
                      (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0), \
                      (const double*)nullptr, (double*)nullptr, rhs, diag, omega, (const double*)nullptr, 0LL, beta)
+  if (csp_on(a)) {
+    const double* xp = X.col(0);
+    double* yp = Y.col(0);
+    if (epi == 1) launch_csp<false, 1>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 2) launch_csp<false, 2>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 3) launch_csp<false, 3>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 4) launch_csp<false, 4>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 5) launch_csp<false, 5>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else launch_csp<false, 0>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+  } else
   if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else if (epi == 3) MXG_CS_EPI(3); else if (epi == 4) MXG_CS_EPI(4);
   else if (epi == 5) MXG_CS_EPI(5); else MXG_CS_EPI(0);
 #undef MXG_CS_EPI
@@ -1652,7 +2078,9 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
   const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
   const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
   (void)hipGetLastError();
-  if ((a->kernel & 0x1000000) && a->ncs == a->npipe)
+  if ((a->kernel & 0x1000000) && a->ncs == a->npipe && csp_on(a))
+    launch_csp<true, 0>(c, a, (const double*)X.col(0), Y.col(0), (const double*)x->colptr(0), a->d_dotpartial, nullptr, nullptr, 0.0, 0.0);
+  else if ((a->kernel & 0x1000000) && a->ncs == a->npipe)
     hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
                        (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
                        (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0),

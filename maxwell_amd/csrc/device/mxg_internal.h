@@ -131,6 +131,7 @@ struct mxg_csr {
   int pipe_geo = -1;
   double* d_dotpartial = nullptr;   // per-block partials of the fused SpMV + dot
   unsigned short* d_roff = nullptr; // row-gather kernel: 16-bit in-block row offsets (nrows + nblocks + 1)
+  unsigned short* d_roff16 = nullptr; // persistent row-gather kernel: the same, 264 entries per block (16-byte aligned pieces)
   // compressed-stream kernel (mxg_csr_compress): 32-byte block descriptors + packed per-block streams
   void* d_csdesc = nullptr;
   unsigned char* d_csstream = nullptr;

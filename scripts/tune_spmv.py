@@ -12,7 +12,7 @@ sim = mx.Sim.pillbox(n)
 A = sim.to_device(ctx, "vecLapl", shift=0.05 * (2 * np.pi) ** 2)
 X = mx.MultiVec(ctx, A.ncols, 1); Y = mx.MultiVec(ctx, A.nrows, 1); X.random(1)
 alg = A.apply_bytes(1)
-names = {0x4000: "xwin 256x8", 0x8000: "xwin 256x4", 0: "stream nt+xcd 256x8", 2: "stream plain-loads", 4: "stream no-xcd", 6: "stream plain,no-xcd", 1: "vector8",
+names = {0x750000: "row-gather (r01 default)", 0x2750000: "persistent row-gather, LDS-DMA nt", 0x6750000: "persistent row-gather, LDS-DMA", 0x4000: "xwin 256x8", 0x8000: "xwin 256x4", 0: "stream nt+xcd 256x8", 2: "stream plain-loads", 4: "stream no-xcd", 6: "stream plain,no-xcd", 1: "vector8",
          0x10: "stream 512x8", 0x20: "stream 256x4", 0x30: "stream 256x16"}
 res = {}
 for rnd in range(3):

@@ -52,6 +52,28 @@ def test_spmm_block_of_vectors(ctx, oracle_pillbox12, rng, k):
     assert np.array_equal(_apply(ctx, m, x), cref.spmv(m, x))
 
 
+@pytest.mark.parametrize("code", [0x2750000, 0x750000])
+def test_spmm_views_every_row_gather_kernel(ctx, oracle_pillbox16, rng, code):
+    """Blocks of vectors and views of scattered columns through the persistent (LDS-DMA, double-buffered) and the
+    one-block-per-workgroup row-gather kernels; many more row blocks than workgroup slots per XCD would need
+    a bigger matrix - tests/test_fullsize_gpu.py covers that."""
+    _, o = oracle_pillbox16
+    m = o["curlCurl"]
+    x = rng.uniform(-1, 1, (m.shape[1], 6))
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    A.set_kernel(code)
+    X = mx.MultiVec.from_numpy(ctx, x)
+    Y = mx.MultiVec(ctx, m.shape[0], 6)
+    A.apply(X, Y)
+    assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+    Y.fill(0.0)
+    A.apply(X.view([4, 5, 0, 2]), Y.view([1, 2, 5, 0]))
+    got = Y.to_numpy()
+    assert np.array_equal(got[:, [1, 2, 5, 0]], cref.spmv(m, x[:, [4, 5, 0, 2]])) and np.all(got[:, [3, 4]] == 0)
+    A.apply(X, X)                                        # aliasing: works from a copy of x
+    assert np.array_equal(X.to_numpy(), cref.spmv(m, x))
+
+
 def test_apply_in_place_aliasing(ctx, oracle_pillbox12, rng):
     """apply(x, x) is used by the reference (src/MxMagWaveOp.cpp:650,1249)."""
     _, o = oracle_pillbox12
@@ -156,7 +178,7 @@ def test_full_size_linearity_and_constant_nullspace(ctx):
     assert p.norm2()[0] < 1e-9 * b.norm2()[0]
 
 
-@pytest.mark.parametrize("code", [0x10000, 0x20000, 0x710000, 0x750000, 0x460000, 0x410000, 0x4000, 0x8000, 0x0, 0x2, 0x4, 0x10, 0x20, 0x30, 0x540, 0x840, 0x480, 0x180, 0x1])
+@pytest.mark.parametrize("code", [0x2750000, 0x6750000, 0x2450000, 0x2050000, 0x10000, 0x20000, 0x710000, 0x750000, 0x460000, 0x410000, 0x4000, 0x8000, 0x0, 0x2, 0x4, 0x10, 0x20, 0x30, 0x540, 0x840, 0x480, 0x180, 0x1])
 def test_every_kernel_variant_bit_exact(ctx, oracle_pillbox16, rng, code):
     """All tuning variants (plain / non-temporal loads, XCD remap, block geometries, the
     software-pipelined persistent kernel) must give the same bits as the serial row loop;
@@ -188,7 +210,7 @@ def test_pipelined_kernel_ragged(ctx, rng):
     m = sp.csr_matrix((rng.uniform(-1, 1, len(indices)), indices, indptr), shape=(n, n))
     x = rng.uniform(-1, 1, n)
     want = cref.spmv(m, x)
-    for code in (0x10000, 0x20000, 0x4000, 0x8000, 0x540, 0x480):
+    for code in (0x2750000, 0x6750000, 0x10000, 0x20000, 0x4000, 0x8000, 0x540, 0x480):
         A = mx.CsrMatrix.from_scipy(ctx, m)
         A.set_kernel(code)
         X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, n, 1)
@@ -300,10 +322,13 @@ def test_config3_cylinder_and_config5_sphere_geometries(ctx, rng):
             assert np.array_equal(Y.to_numpy(), cref.spmv(host, x))
 
 
-def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng):
+@pytest.mark.parametrize("csp", ["1", "0"])
+def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, csp, monkeypatch):
     """mxg_csr_compress: 16-bit band codes + 8-bit value-table indices per row block; every operator of
     the pillbox (bulk blocks pack, cut-cell blocks fall back to plain CSR rows), SpMV and SpMM, and the
-    fused SpMV+dot of CG give the same bits as the serial row loop."""
+    fused SpMV+dot of CG give the same bits as the serial row loop.  csp = 1: the persistent kernel with a
+    loader wave (k_spmv_csp, the default); 0: one block per workgroup (k_spmv_cs)."""
+    monkeypatch.setenv("MXG_CSP", csp)
     _, o = oracle_pillbox16
     packed_any = False
     for name in ("vecLapl", "scaLapl", "curlCurl", "curlE", "divB", "gradPsi", "mRhs"):
@@ -337,8 +362,10 @@ def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng):
     assert np.abs(sols[0][1] - sols[1][1]).max() <= 1e-8 * np.abs(sols[0][1]).max()
 
 
-def test_compressed_stream_fallbacks(ctx, rng):
+@pytest.mark.parametrize("csp", ["1", "0"])
+def test_compressed_stream_fallbacks(ctx, rng, csp, monkeypatch):
     """Blocks with more than 16 column bands or 256 distinct values, empty rows and an over-long row."""
+    monkeypatch.setenv("MXG_CSP", csp)
     n = 9000
     rows = [rng.choice(n, size=int(c), replace=False) for c in rng.integers(0, 12, size=n)]   # scattered columns
     rows[5] = np.arange(n)[:2600]                        # longer than a block
