@@ -554,18 +554,25 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
     const double* __restrict__ xg = HALO ? xghost + j * ldghost : nullptr;
     double sum = 0.0;
     for (int q0 = o0; q0 < o1; q0 += CH) {
+      // branch-free chunk (indices clamped into the row): CH column / value reads and CH gathers issued back to back
       double v[CH], xv[CH];
+      int cc[CH];
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        const bool on = q0 + i < o1;
-        const int cc = on ? scol[q0 + i] : 0;
-        v[i] = on ? sval[q0 + i] : 0.0;
-        if (HALO) xv[i] = on ? (cc >= nowned ? xg[cc - nowned] : x[cc]) : 0.0;
-        else xv[i] = on ? x[cc] : 0.0;
+        const int q = min(q0 + i, o1 - 1);
+        cc[i] = scol[q];
+        v[i] = sval[q];
       }
 #pragma unroll
-      for (int i = 0; i < CH; ++i)
-        if (q0 + i < o1) sum += v[i] * xv[i];
+      for (int i = 0; i < CH; ++i) {
+        if (HALO) xv[i] = cc[i] >= nowned ? xg[cc[i] - nowned] : x[cc[i]];
+        else xv[i] = x[cc[i]];
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const double s2 = sum + v[i] * xv[i];
+        sum = q0 + i < o1 ? s2 : sum;
+      }
     }
     if ((int)threadIdx.x < d.nr) __builtin_nontemporal_store(sum, Y.col(j) + d.r0 + threadIdx.x);
     if (DOT && j == 0) {
@@ -746,15 +753,24 @@ __global__ __launch_bounds__(256) void k_spmv_rgp(
 struct CsDesc {
   long long base;   // rowptr[r0]
   long long soff;   // byte offset of the block's packed stream (16-byte aligned); -1: plain CSR block
-  int r0, nrnv, nnzb, rb;   // nrnv = rows (<= 256) | distinct values << 16; rb = position of the block's row offsets in roff[]
+  int r0, nrnv, nnzb, rb;   // nrnv = rows (<= 256) | distinct values << 16 | flags; rb = position of the block's row offsets in roff[]
+  int rec16, pad;           // length of the block's record in 16-byte units (the persistent kernel's loader)
   __host__ __device__ inline int nr() const { return nrnv & 0xffff; }
   __host__ __device__ inline int nval() const { return (nrnv >> 16) & 0x1ff; }
   // the block's record holds only its row offsets (more bands / distinct values / bytes than the packed form takes):
   // columns and values come from the CSR arrays
   __host__ __device__ inline bool roff_only() const { return (nrnv >> 30) & 1; }
+  __host__ __device__ inline bool patterned() const { return (nrnv >> 29) & 1; }
 };
-constexpr int CS_ROFF_ONLY = 1 << 30;
-static_assert(sizeof(CsDesc) == 32, "descriptor layout");
+constexpr int CS_ROFF_ONLY = 1 << 30;   // generic rows read the CSR arrays in place (row offsets are those of the CSR arrays)
+constexpr int CS_PATTERNED = 1 << 29;   // the record has a pattern table + per-row pattern ids (persistent kernel only)
+constexpr int CS_HAS_GENERIC = 1 << 28; // patterned record with a generic part for the rows no pattern covers
+// Pattern table of a patterned record: most rows of a Yee operator's block repeat a handful of (column - row, value)
+// sequences (the bulk stencil, per z-line); such a row costs one byte instead of 3 bytes per entry.
+constexpr int CS_NPAT = 4, CS_PLEN = 8;
+constexpr int CS_PAT_BYTES = CS_NPAT * CS_PLEN * 4 + CS_NPAT * CS_PLEN * 8 + 16;   // deltas, values, lengths
+constexpr int CS_ROWPAT_BYTES = 256;
+static_assert(sizeof(CsDesc) == 40, "descriptor layout");
 constexpr int CS_SEGS = 16, CS_OFFBITS = 12, CS_MAXVAL = 256;
 // every record starts with a 32-byte header {r0, nrnv (as in CsDesc), nnzb, 0, base, 0}: the persistent kernel's
 // consumer waves take a block's shape from LDS and never wait for a global descriptor
@@ -950,147 +966,310 @@ template <> __device__ inline void csp_wait_pieces<0>() { asm volatile("s_waitcn
 template <> __device__ inline void csp_wait_pieces<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 template <> __device__ inline void csp_wait_pieces<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
 template <> __device__ inline void csp_wait_pieces<24>() { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+template <> __device__ inline void csp_wait_pieces<32>() { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
+template <> __device__ inline void csp_wait_pieces<48>() { asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); }
 
-template <int CH, bool DOT, int EPI, int D>
+// One row of one staged record, in two phases so that a thread can have the gathers of several rows (of several
+// records) in flight before it consumes any.  The consumers are instruction-bound (rocprofv3: SIMDs ~75 % busy at
+// 0.20 ms, 127 VALU instructions per row with per-entry selects and 64-bit address arithmetic), so the pattern path
+// is kept to one add, one gather and two products per entry: every pattern of a record has the same length (a
+// wave-uniform loop bound from the header), deltas are stored in BYTES and x is addressed as base + 32-bit offset.
+template <bool HALO>
+struct CspRow {
+  double xv[CS_PLEN];       // gathered x of the pattern's entries (the values stay in LDS until they are needed)
+  double sum;
+  int plen, r0, nr, nrnv, nnzg, pat, o0, o1;
+  bool live, generic, longrow, patrow, packed;
+  const unsigned char* rec;
+  const unsigned char* gen;
+
+  // phase 1a: header and pattern id (LDS reads only, so that the compiler can batch them over the thread's rows)
+  __device__ inline void head(const unsigned char* record, int t, bool present) {
+    rec = record;
+    const uint4v h = *reinterpret_cast<const uint4v*>(rec);
+    r0 = __builtin_amdgcn_readfirstlane((int)h.x);
+    nrnv = __builtin_amdgcn_readfirstlane((int)h.y);
+    nnzg = __builtin_amdgcn_readfirstlane((int)h.z);
+    plen = __builtin_amdgcn_readfirstlane((int)h.w);
+    nr = nrnv & 0xffff;
+    longrow = present && nnzg > RgCfgA::NNZ_CAP;
+    live = present && !longrow && t < nr;
+    sum = 0.0; pat = 0; generic = live; patrow = false;
+    gen = rec + CS_HDR;
+    if (nrnv & CS_PATTERNED) {
+      gen += CS_PAT_BYTES + CS_ROWPAT_BYTES;
+      // a row that repeats one of the block's patterns: its entries are (row + delta_i, value_i) from the pattern
+      // table (the same LDS address for every lane with that pattern: broadcast reads)
+      const int p = live ? rec[CS_HDR + CS_PAT_BYTES + t] : 0xFF;
+      generic = live && p == 0xFF && (nrnv & CS_HAS_GENERIC) != 0;
+      patrow = p != 0xFF;
+      pat = patrow ? p : 0;
+    }
+    packed = generic && !(nrnv & CS_ROFF_ONLY);
+    o0 = 0; o1 = 0;
+    if (packed) {
+      const int nvpad = (((nrnv >> 16) & 0x1ff) + 1) & ~1;
+      const unsigned short* sroff = reinterpret_cast<const unsigned short*>(
+          gen + CS_SEGS * 4 + nvpad * 8 + ((nnzg + 7) >> 3) * 16 + ((nnzg + 15) >> 4) * 16);
+      o0 = sroff[t]; o1 = sroff[t + 1];
+    }
+  }
+
+  // phase 1b: the gathers of the row's first CS_PLEN entries.
+  // The loads are inline asm: hipcc cannot prove that a load issued under one exec mask is consumed under the same
+  // mask later and guards the re-use of its destination registers with s_waitcnt vmcnt(0) - in front of every entry,
+  // which serialises the row's gathers.  Issued this way they are invisible to its counters; the kernel waits once
+  // before any of them is consumed.  ONE asm statement per entry, whatever kind of row: two statements in the arms
+  // of a branch would be merged by register copies placed right behind them - copies of registers whose loads are
+  // still in flight.
+  __device__ inline void gather(int t, const double* __restrict__ x, const double* __restrict__ xg, int nowned) {
+    unsigned off[CS_PLEN];
+#pragma unroll
+    for (int i = 0; i < CS_PLEN; ++i) off[i] = 0;
+    int nload = 0;
+    if (patrow) {
+      const uint4v* dp = reinterpret_cast<const uint4v*>(rec + CS_HDR + pat * (CS_PLEN * 4));
+      const uint4v da = dp[0], db = dp[1];               // the pattern's eight byte deltas: two 16-byte LDS reads
+      const unsigned dl8[CS_PLEN] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+      const unsigned off0 = (unsigned)(r0 + t) << 3;
+#pragma unroll
+      for (int i = 0; i < CS_PLEN; ++i) off[i] = off0 + dl8[i];
+      nload = plen;
+    } else if (packed) {
+      // a row no pattern covers: indices clamped into the row (an empty row gathers x[0] and discards it)
+      const int nvpad = (((nrnv >> 16) & 0x1ff) + 1) & ~1;
+      const int* sseg = reinterpret_cast<const int*>(gen);
+      const unsigned short* scode = reinterpret_cast<const unsigned short*>(gen + CS_SEGS * 4 + nvpad * 8);
+      const int qlast = o1 > o0 ? o1 - 1 : o0;
+      unsigned code[CS_PLEN];
+#pragma unroll
+      for (int i = 0; i < CS_PLEN; ++i) code[i] = scode[min(o0 + i, qlast)];
+#pragma unroll
+      for (int i = 0; i < CS_PLEN; ++i) {
+        const int cc = sseg[code[i] >> CS_OFFBITS] + (int)(code[i] & ((1u << CS_OFFBITS) - 1u));
+        off[i] = (unsigned)(o0 + i < o1 ? cc : 0) << 3;
+      }
+      nload = CS_PLEN;
+    }
+#pragma unroll
+    for (int i = 0; i < CS_PLEN; ++i)
+      if (i < nload) {
+        if (HALO) {
+          const unsigned nb8 = (unsigned)nowned << 3;
+          const char* addr = off[i] >= nb8 ? reinterpret_cast<const char*>(xg) + (off[i] - nb8)
+                                           : reinterpret_cast<const char*>(x) + off[i];
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xv[i]) : "v"(addr));
+        } else {
+          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(xv[i]) : "v"(off[i]), "s"(x));
+        }
+      }
+  }
+
+  // phase 2: rows no pattern covers (their own gathers, consumed at once), then the pattern's products in storage order
+  template <int CH, typename XAT>
+  __device__ inline void finish(int t, const int* __restrict__ colidx, const double* __restrict__ vals, XAT xat) {
+    if (generic) {
+      const int nvpad = (((nrnv >> 16) & 0x1ff) + 1) & ~1;
+      if (packed) {
+        const int* sseg = reinterpret_cast<const int*>(gen);
+        const double* svtab = reinterpret_cast<const double*>(gen + CS_SEGS * 4);
+        const unsigned short* scode = reinterpret_cast<const unsigned short*>(gen + CS_SEGS * 4 + nvpad * 8);
+        const unsigned char* svid = gen + CS_SEGS * 4 + nvpad * 8 + ((nnzg + 7) >> 3) * 16;
+        const int qlast = o1 > o0 ? o1 - 1 : o0;
+        // first chunk: gathered in phase 1
+        int vid[CS_PLEN];
+#pragma unroll
+        for (int i = 0; i < CS_PLEN; ++i) vid[i] = svid[min(o0 + i, qlast)];
+#pragma unroll
+        for (int i = 0; i < CS_PLEN; ++i) {
+          asm volatile("" : "+v"(xv[i]));
+          const double s2 = sum + svtab[vid[i]] * xv[i];
+          sum = o0 + i < o1 ? s2 : sum;
+        }
+        // longer rows (wall rows have up to 15 entries): further chunks of CH, each a batch of gathers
+        for (int q0 = o0 + CS_PLEN; q0 < o1; q0 += CH) {
+          double gv[CH], gx[CH];
+          unsigned code[CH];
+          int vd[CH];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const int q = min(q0 + i, qlast);
+            code[i] = scode[q];
+            vd[i] = svid[q];
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            gx[i] = xat(sseg[code[i] >> CS_OFFBITS] + (int)(code[i] & ((1u << CS_OFFBITS) - 1u)));
+            gv[i] = svtab[vd[i]];
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const double s2 = sum + gv[i] * gx[i];
+            sum = q0 + i < o1 ? s2 : sum;
+          }
+        }
+      } else {
+        const long long base = reinterpret_cast<const long long*>(rec)[2];
+        const unsigned short* sroff = reinterpret_cast<const unsigned short*>(gen + CS_SEGS * 4);
+        const int c0 = sroff[t], c1 = sroff[t + 1];
+#pragma unroll 1
+        for (long long q = base + c0; q < base + c1; ++q) sum += vals[q] * xat(colidx[q]);
+      }
+    } else if (patrow) {
+      // the pattern's eight values in four 16-byte LDS reads (broadcast), then the products in storage order
+      const dbl2* pv = reinterpret_cast<const dbl2*>(rec + CS_HDR + CS_NPAT * CS_PLEN * 4 + pat * (CS_PLEN * 8));
+      const dbl2 v01 = pv[0], v23 = pv[1], v45 = pv[2], v67 = pv[3];
+      const double v[CS_PLEN] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y, v67.x, v67.y};
+#pragma unroll
+      for (int i = 0; i < CS_PLEN; ++i)
+        if (i < plen) {
+          asm volatile("" : "+v"(xv[i]));                   // the value the asm load delivered (after the kernel's wait)
+          sum += v[i] * xv[i];
+        }
+    }
+  }
+};
+
+// diagnostics (MXG_CSP_STAMPS=1): per-phase s_memtime sums of workgroup 0's loader wave and first consumer wave
+__device__ unsigned long long g_csp_stamps[16];
+__device__ inline unsigned long long csp_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+
+// NB records per iteration (all their pattern gathers in flight together), ring of D iterations' worth of slots
+template <int CH, bool DOT, int EPI, int D, bool HALO = false, int NB = 2, bool STAMP = false>
 __global__ __launch_bounds__(CSP_THREADS) void k_spmv_csp(
     const CsDesc* __restrict__ desc, long long nblocks, const unsigned char* __restrict__ stream,
     const int* __restrict__ colidx, const double* __restrict__ vals,
     const double* __restrict__ x, double* __restrict__ y,
     const double* __restrict__ xdot, double* __restrict__ partial,
-    const double* __restrict__ rhs, const double* __restrict__ diag, double omega, double beta) {
-  __shared__ __attribute__((aligned(16))) unsigned char ring[D][CSP_SLOT];
-  __shared__ double sred[2][4];
+    const double* __restrict__ rhs, const double* __restrict__ diag, double omega, double beta,
+    const double* __restrict__ xg, int nowned) {
+  auto xat = [&](int cc) -> double { return (HALO && cc >= nowned) ? xg[cc - nowned] : x[cc]; };
+  __shared__ __attribute__((aligned(16))) unsigned char ring[D * NB][CSP_SLOT];
+  __shared__ double sred[2][NB][4];
+  // an XCD's contiguous eighth of the blocks, in groups of NB consecutive blocks dealt to its workgroups in turn
   const long long W = gridDim.x / MXG_NUM_XCD;
   const long long per = (nblocks + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
   const long long xcd = blockIdx.x % MXG_NUM_XCD;
-  const long long first = xcd * per + blockIdx.x / MXG_NUM_XCD;
+  const long long first = xcd * per + (blockIdx.x / MXG_NUM_XCD) * NB;
   const long long last = min((xcd + 1) * per, nblocks);
+  const long long step = W * NB;
   if (first >= last) return;
   const int t = threadIdx.x;
+  constexpr int PIECES = NB * (CSP_SLOT / 1024);          // DMA pieces per iteration
   if (t >= 256) {
     // ------------------------------------------------------------------ loader wave
     const int lane = t & 63;
-    // where block bb's record is and how long: (offset, bytes); (0, 0) past the end -> eight dummy pieces of the
-    // stream's first bytes keep the vmcnt arithmetic static
-    auto where = [&](long long bb, long long& soff, int& bytes) {
-      soff = 0; bytes = 0;
-      if (bb < last) {
-        soff = desc[bb].soff;
-        const int nnzb = desc[bb].nnzb, nrnv = desc[bb].nrnv;
-        bytes = nnzb > RgCfgA::NNZ_CAP ? CS_HDR : cs_record_bytes(nnzb, (nrnv >> 16) & 0x1ff, nrnv & 0xffff, (nrnv >> 30) & 1);
+    // group g of this workgroup = blocks g .. g + NB - 1 (those < last); a missing block -> dummy pieces of the
+    // stream's first bytes, which keep the vmcnt arithmetic static
+    long long so[NB], so_next[NB];
+    int by[NB], by_next[NB];
+    auto where = [&](long long g, long long* soff, int* bytes) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        soff[j] = 0; bytes[j] = 0;
+        if (g + j < last) { soff[j] = desc[g + j].soff; bytes[j] = desc[g + j].rec16 * 16; }
       }
     };
-    auto issue = [&](long long soff, int bytes, int slot) {
-      const unsigned char* rec = stream + soff;
+    auto issue = [&](const long long* soff, const int* bytes, int slot0) {
 #pragma unroll
-      for (int p = 0; p < CSP_SLOT / 1024; ++p) {          // eight pieces, all 64 lanes always active
-        const int off = 1024 * p + 16 * lane;
-        lds_dma16<1>(rec + (off < bytes ? off : 0), ring[slot] + 1024 * p);
+      for (int j = 0; j < NB; ++j) {
+        const unsigned char* rec = stream + soff[j];
+#pragma unroll
+        for (int p = 0; p < CSP_SLOT / 1024; ++p) {        // eight pieces per record, all 64 lanes always active
+          const int off = 1024 * p + 16 * lane;
+          lds_dma16<1>(rec + (off < bytes[j] ? off : 0), ring[slot0 + j] + 1024 * p);
+        }
       }
     };
-    long long so, so_next;
-    int by, by_next;
 #pragma unroll
-    for (int j = 0; j < D - 1; ++j) { where(first + j * W, so, by); issue(so, by, j); }
-    where(first + (D - 1) * W, so_next, by_next);
+    for (int j = 0; j < D - 1; ++j) { where(first + j * step, so, by); issue(so, by, j * NB); }
+    where(first + (D - 1) * step, so_next, by_next);
     int it = 0;
-    for (long long b = first; b < last; b += W, ++it) {
-      csp_wait_pieces<8 * (D - 2)>();                       // block `it` has landed, D - 2 younger ones stay in flight
-      asm volatile("s_barrier" ::: "memory");               // consumers: slot it % D is yours, slot (it - 1) % D is mine
-      so = so_next; by = by_next;
-      where(b + D * W, so_next, by_next);                 // descriptor of the block after next: a whole iteration ahead
-      issue(so, by, (it + D - 1) % D);
+    unsigned long long tw = 0, tb = 0, ti = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (long long g = first; g < last; g += step, ++it) {
+      if (STAMP) t0 = csp_now();
+      csp_wait_pieces<PIECES * (D - 2)>();                  // group `it` has landed, D - 2 younger ones stay in flight
+      if (STAMP) t1 = csp_now();
+      asm volatile("s_barrier" ::: "memory");               // consumers: group it % D is yours, (it - 1) % D is mine
+      if (STAMP) t2 = csp_now();
+#pragma unroll
+      for (int j = 0; j < NB; ++j) { so[j] = so_next[j]; by[j] = by_next[j]; }
+      where(g + D * step, so_next, by_next);              // descriptors of the group after next: an iteration ahead
+      issue(so, by, ((it + D - 1) % D) * NB);
+      if (STAMP) { t3 = csp_now(); tw += t1 - t0; tb += t2 - t1; ti += t3 - t2; }
     }
     csp_wait_pieces<0>();
     asm volatile("s_barrier" ::: "memory");
+    if (STAMP && blockIdx.x == 0 && lane == 0) { g_csp_stamps[0] = tw; g_csp_stamps[1] = tb; g_csp_stamps[2] = ti; g_csp_stamps[3] = (unsigned long long)it; }
     return;
   }
-  // -------------------------------------------------------------------- consumer waves: one row per thread
+  // -------------------------------------------------------------------- consumer waves: one row per record per thread
   int it = 0;
-  long long bprev = -1, rprev = 0;
-  bool lprev = false;
-  for (long long b = first; b < last; b += W, ++it) {
-    wg_barrier_lds();                                     // the record of block b is in ring[it % D]
-    if (t == 0 && bprev >= 0) {                           // finish the previous block's cross-wave sums
-      const double* sp = sred[(it - 1) & 1];
+  long long gprev = -1;
+  int rprev[NB];
+  bool lprev[NB], fprev[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) { rprev[j] = 0; lprev[j] = false; fprev[j] = false; }
+  auto flush = [&](int itp) {                              // finish the previous group's cross-wave sums (thread 0)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (!fprev[j]) continue;
+      const double* sp = sred[itp & 1][j];
       const double tot = ((sp[0] + sp[1]) + sp[2]) + sp[3];
-      if (lprev) { y[rprev] = cs_epilogue<EPI>(tot, rprev, x, rhs, diag, omega, beta, y); if (DOT) partial[bprev] = tot * xdot[rprev]; }
-      else if (DOT) partial[bprev] = tot;
+      if (lprev[j]) { y[rprev[j]] = cs_epilogue<EPI>(tot, rprev[j], x, rhs, diag, omega, beta, y); if (DOT) partial[gprev + j] = tot * xdot[rprev[j]]; }
+      else if (DOT) partial[gprev + j] = tot;
     }
-    const unsigned char* rec = ring[it % D];
-    const int* hdr = reinterpret_cast<const int*>(rec);
-    const int r0 = hdr[0], nrnv = hdr[1], nnzb = hdr[2];
-    const int nr = nrnv & 0xffff, nvpad = (((nrnv >> 16) & 0x1ff) + 1) & ~1;
-    const bool roff_only = (nrnv >> 30) & 1;
-    const bool longrow = nnzb > RgCfgA::NNZ_CAP;
-    double part = 0.0;
-    if (longrow) {
-      // one over-long row: the four waves share it, wave sums are combined in wave order after the next barrier
-      const long long base = reinterpret_cast<const long long*>(rec)[2];
-#pragma unroll 1
-      for (long long q = base + t; q < base + nnzb; q += 256) part += vals[q] * x[colidx[q]];
-    } else if (t < nr) {
-      double sum = 0.0;
-      if (!roff_only) {
-        const int* sseg = reinterpret_cast<const int*>(rec + CS_HDR);
-        const double* svtab = reinterpret_cast<const double*>(rec + CS_HDR + CS_SEGS * 4);
-        const unsigned short* scode = reinterpret_cast<const unsigned short*>(rec + CS_HDR + CS_SEGS * 4 + nvpad * 8);
-        const unsigned char* svid = rec + CS_HDR + CS_SEGS * 4 + nvpad * 8 + ((nnzb + 7) >> 3) * 16;
-        const unsigned short* sroff = reinterpret_cast<const unsigned short*>(svid + ((nnzb + 15) >> 4) * 16);
-        const int o0 = sroff[t], o1 = sroff[t + 1];
-        // Branch-free head: LDS indices are clamped into the row (an empty row reads slot bytes it never uses and
-        // gathers x[0]), so the compiler batches the CH code reads, then the band origins, value ids and table reads,
-        // and every gather of the row is in flight before the first product.
-        const int qlast = o1 > o0 ? o1 - 1 : o0;
-        double v[CH], xv[CH];
-        unsigned code[CH];
-        int vid[CH];
+  };
+  unsigned long long cb = 0, cg = 0, cw = 0, cf = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (long long g = first; g < last; g += step, ++it) {
+    if (STAMP) c0 = csp_now();
+    wg_barrier_lds();                                     // the records of group g are in ring[(it % D) * NB ..]
+    if (STAMP) c1 = csp_now();
+    if (t == 0 && gprev >= 0) flush(it - 1);
+    CspRow<HALO> row[NB];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const int q = min(o0 + i, qlast);
-          code[i] = scode[q];
-          vid[i] = svid[q];
-        }
+    for (int j = 0; j < NB; ++j) row[j].head(ring[(it % D) * NB + j], t, g + j < last);
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const int cc = sseg[code[i] >> CS_OFFBITS] + (int)(code[i] & ((1u << CS_OFFBITS) - 1u));
-          xv[i] = x[o0 + i < o1 ? cc : 0];
-          v[i] = svtab[vid[i]];
-        }
+    for (int j = 0; j < NB; ++j) row[j].gather(t, x, xg, nowned);
+    if (STAMP) c2 = csp_now();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every pattern gather of this thread's NB rows has landed
+    if (STAMP) { c3 = csp_now(); cb += c1 - c0; cg += c2 - c1; cw += c3 - c2; }
+    double part[NB];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const double s2 = sum + v[i] * xv[i];
-          sum = o0 + i < o1 ? s2 : sum;
-        }
+    for (int j = 0; j < NB; ++j) {
+      part[j] = 0.0;
+      if (row[j].longrow) {
+        // one over-long row: the four waves share it, wave sums are combined in wave order after the next barrier
+        const long long base = reinterpret_cast<const long long*>(row[j].rec)[2];
 #pragma unroll 1
-        for (int q = o0 + CH; q < o1; ++q) {              // longer rows: the tail, in storage order
-          const unsigned code1 = scode[q];
-          sum += svtab[svid[q]] * x[sseg[code1 >> CS_OFFBITS] + (int)(code1 & ((1u << CS_OFFBITS) - 1u))];
-        }
-      } else {
-        const long long base = reinterpret_cast<const long long*>(rec)[2];
-        const unsigned short* sroff = reinterpret_cast<const unsigned short*>(rec + CS_HDR + CS_SEGS * 4);
-        const int o0 = sroff[t], o1 = sroff[t + 1];
-#pragma unroll 1
-        for (long long q = base + o0; q < base + o1; ++q) sum += vals[q] * x[colidx[q]];
+        for (long long q = base + t; q < base + row[j].nnzg; q += 256) part[j] += vals[q] * xat(colidx[q]);
+      } else if (row[j].live) {
+        row[j].template finish<CH>(t, colidx, vals, xat);
+        const long long r = (long long)row[j].r0 + t;
+        __builtin_nontemporal_store(cs_epilogue<EPI>(row[j].sum, r, x, rhs, diag, omega, beta, y), y + r);
+        if (DOT) part[j] = row[j].sum * xdot[r];
       }
-      __builtin_nontemporal_store(cs_epilogue<EPI>(sum, (long long)r0 + t, x, rhs, diag, omega, beta, y), y + r0 + t);
-      if (DOT) part = sum * xdot[r0 + t];
     }
-    if (DOT || longrow) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-      if ((t & 63) == 0) sred[it & 1][t >> 6] = part;
+    for (int j = 0; j < NB; ++j) {
+      const bool present = g + j < last;
+      if (present && (DOT || row[j].longrow)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part[j] += __shfl_down(part[j], off, 64);
+        if ((t & 63) == 0) sred[it & 1][j][t >> 6] = part[j];
+      }
+      fprev[j] = present && (DOT || row[j].longrow); rprev[j] = row[j].r0; lprev[j] = row[j].longrow;
     }
-    bprev = (DOT || longrow) ? b : -1; rprev = r0; lprev = longrow;
+    gprev = g;
+    if (STAMP) cf += csp_now() - c3;
   }
   wg_barrier_lds();
-  if (t == 0 && bprev >= 0) {
-    const double* sp = sred[(it - 1) & 1];
-    const double tot = ((sp[0] + sp[1]) + sp[2]) + sp[3];
-    if (lprev) { y[rprev] = cs_epilogue<EPI>(tot, rprev, x, rhs, diag, omega, beta, y); if (DOT) partial[bprev] = tot * xdot[rprev]; }
-    else if (DOT) partial[bprev] = tot;
-  }
+  if (t == 0 && gprev >= 0) flush(it - 1);
+  if (STAMP && blockIdx.x == 0 && t == 0) { g_csp_stamps[4] = cb; g_csp_stamps[5] = cg; g_csp_stamps[6] = cw; g_csp_stamps[7] = cf; }
 }
 
 
@@ -1182,7 +1361,7 @@ void launch_stream(mxg_ctx* c, const mxg_csr* a, const MvDesc& X, const MvDesc& 
 template <typename CFG>
 static int build_xwin(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx);
 static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr);
-constexpr int MXG_KERNEL_DEFAULT = 0x750000;   // row-gather 2048 nnz, gather chunk 7, 16-bit in-block row offsets
+constexpr int MXG_KERNEL_DEFAULT = 0x2750000;  // persistent LDS-DMA row-gather (2048-nnz blocks, gather chunk 7, 16-bit in-block row offsets)
 
 extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, int64_t nghost,
                               const int64_t* rowptr, const int32_t* colidx, const double* vals,
@@ -1282,6 +1461,9 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (a->d_dotpartial) hipFree(a->d_dotpartial);
   if (a->d_roff) hipFree(a->d_roff);
   if (a->d_roff16) hipFree(a->d_roff16);
+  if (a->d_rowpid) hipFree(a->d_rowpid);
+  if (a->d_patdict) hipFree(a->d_patdict);
+  if (a->d_grows) hipFree(a->d_grows);
   if (a->d_csdesc) hipFree(a->d_csdesc);
   if (a->d_csstream) hipFree(a->d_csstream);
   if (a->d_xwdesc) hipFree(a->d_xwdesc);
@@ -1441,7 +1623,7 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
     desc[b] = d;
   }
   if (a->d_blkdesc) hipFree(a->d_blkdesc);
-  if (a->d_dotpartial) { hipFree(a->d_dotpartial); a->d_dotpartial = nullptr; }
+  if (a->d_dotpartial) { hipFree(a->d_dotpartial); a->d_dotpartial = nullptr; a->dotpartial_cap = 0; }
   if (a->d_roff) { hipFree(a->d_roff); a->d_roff = nullptr; }
   if (geo >= 10) {
     // row-gather kernel: in-block row offsets as uint16 (nr + 1 per block, block b at r0 + b);
@@ -1498,50 +1680,160 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
 }
 
 
-// Packed streams for k_spmv_cs over the row blocks of the row-gather geometry (RgCfgA).
-static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const double* va) {
+// MXG_CSP=1: the persistent record kernel with a loader wave (k_spmv_csp) instead of one block per workgroup (k_spmv_cs).
+// Opt-in: at 256^3 it runs 0.24 ms against 0.205 ms - its consumer waves are latency / instruction bound per block,
+// not waiting for the record stream (profiles/r02b/csp_*).
+static bool csp_wanted() { const char* e = getenv("MXG_CSP"); return e && atoi(e) != 0; }
+// MXG_PAT=1: the pattern-dictionary product (mxg_pat.hip).  Opt-in: at 256^3 the scalar Laplacian runs 0.051 ms
+// against 0.068 ms, the vector Laplacian 0.225 against 0.202 (its individual wall rows), the eigen-solve 2.63 s against
+// 2.44 s - every variant lands near 0.2 ms: the 7 gathers per row, not the matrix bytes, set the time.
+static bool pat_wanted() { const char* e = getenv("MXG_PAT"); return e && atoi(e) != 0; }
+static inline bool pat_on(const mxg_csr* a) { return (a->kernel & 0x10000000) != 0 && a->d_rowpid != nullptr; }
+
+// Records for the compressed-stream kernels over the row blocks of the row-gather geometry (RgCfgA).
+//   [header 32 B][pattern table + per-row pattern ids: patterned records only]
+//   [16 band origins][value table][codes][value ids][row offsets]   (the generic part)
+// patterns = false builds the records k_spmv_cs (one block per workgroup) understands.
+static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const double* va, bool patterns) {
   mxg_ctx* c = a->ctx;
   std::vector<int32_t> blk = build_row_blocks(rp, a->nrows, RgCfgA::NNZ_CAP, RgCfgA::ROWS_CAP);
   const size_t nb = blk.size() - 1;
   std::vector<CsDesc> desc(nb);
   std::vector<std::vector<unsigned char> > packs(nb);
+  std::vector<int64_t> npatrows(nb, 0);
   auto work = [&](size_t b0, size_t b1) {
-    std::vector<int32_t> u;
+    std::vector<int32_t> u, gcol;
     std::vector<uint64_t> w;
+    std::vector<double> gval;
+    std::vector<unsigned short> groff;
+    std::vector<std::pair<std::string, int> > sigs;           // (signature bytes, count) of the block's short rows
+    std::vector<int> rowsig;
     for (size_t b = b0; b < b1; ++b) {
       CsDesc d{};
       d.r0 = blk[b]; d.nrnv = blk[b + 1] - blk[b];
       d.base = rp[blk[b]];
       d.nnzb = (int)(rp[blk[b + 1]] - d.base);
-      d.soff = -1;
+      d.soff = 0;           // final offset assigned below
       d.rb = d.r0 + (int)b;
-      desc[b] = d;
       const int nr = d.nrnv;
       std::vector<unsigned char>& pk = packs[b];
-      auto header = [&]() {                                 // after desc[b].nrnv has its flags
-        int32_t h[8] = {d.r0, desc[b].nrnv, d.nnzb, 0, 0, 0, 0, 0};
+      int flags = 0, nval = 0;
+      int hdr_plen = 0;
+      auto finish = [&](int nnz_generic) {                   // header + descriptor once the record is complete
+        d.nrnv = nr | (nval << 16) | flags;
+        int32_t h[8] = {d.r0, d.nrnv, nnz_generic, hdr_plen, 0, 0, 0, 0};
         std::memcpy(h + 4, &d.base, sizeof d.base);
         std::memcpy(pk.data(), h, sizeof h);
+        d.rec16 = (int)(pk.size() / 16);
+        desc[b] = d;
       };
       if (d.nnzb > RgCfgA::NNZ_CAP) {                       // one over-long row: header only, the row is read in place
         pk.assign(CS_HDR, 0);
-        desc[b].soff = 0;
-        header();
+        finish(d.nnzb);
         continue;
       }
-      // every other block has a record that ends with its 16-bit row offsets; the packed form in front of them when
-      // the block's columns fit 16 bands of 2^12, its distinct values a table of 256 and the whole record 8 KiB
-      auto roff_only = [&]() {
-        pk.assign((size_t)cs_record_bytes(d.nnzb, 0, nr, true), 0);
-        unsigned short* ro = reinterpret_cast<unsigned short*>(pk.data() + CS_HDR + CS_SEGS * 4);
-        for (int r = 0; r <= nr; ++r) ro[r] = (unsigned short)(rp[d.r0 + r] - d.base);
-        desc[b].nrnv |= CS_ROFF_ONLY;
-        desc[b].soff = 0;   // final offset assigned below
-        header();
+      // ---- patterns: the most frequent (column - row, value) sequences among the rows of <= CS_PLEN entries
+      std::vector<unsigned char> rowpat;
+      int npat = 0;
+      int32_t pdelta[CS_NPAT][CS_PLEN] = {};
+      double pval[CS_NPAT][CS_PLEN] = {};
+      int32_t plen[CS_NPAT] = {};
+      if (patterns && d.nnzb > 0 && a->ncols_owned + a->nghost < ((int64_t)1 << 28)) {
+        sigs.clear(); rowsig.assign((size_t)nr, -1);
+        std::string sg;
+        for (int t = 0; t < nr; ++t) {
+          const int64_t q0 = rp[d.r0 + t], q1 = rp[d.r0 + t + 1];
+          const int len = (int)(q1 - q0);
+          if (len == 0 || len > CS_PLEN) continue;
+          sg.assign((size_t)len * 12, '\0');
+          bool fits = true;
+          for (int i = 0; i < len; ++i) {
+            const int64_t dl = (int64_t)ci[q0 + i] - (d.r0 + t);
+            if (dl >= (1 << 27) || dl <= -(1 << 27)) { fits = false; break; }
+            const int32_t dl8 = (int32_t)(dl * 8);             // byte delta: the kernel adds it to 8 * row
+            std::memcpy(&sg[(size_t)i * 12], &dl8, 4);
+            std::memcpy(&sg[(size_t)i * 12 + 4], &va[q0 + i], 8);
+          }
+          if (!fits) continue;
+          int found = -1;
+          for (size_t k = 0; k < sigs.size(); ++k) if (sigs[k].first == sg) { found = (int)k; break; }
+          if (found < 0) { if (sigs.size() >= 64) continue; sigs.emplace_back(sg, 0); found = (int)sigs.size() - 1; }
+          ++sigs[(size_t)found].second;
+          rowsig[(size_t)t] = found;
+        }
+        // every pattern of a record has the same length (the kernel's loop bound is wave-uniform): the length most
+        // rows have
+        int64_t bylen[CS_PLEN + 1] = {};
+        for (const auto& sgk : sigs) bylen[sgk.first.size() / 12] += sgk.second;
+        int best_len = 1;
+        for (int l = 2; l <= CS_PLEN; ++l) if (bylen[l] > bylen[best_len]) best_len = l;
+        std::vector<int> order;
+        for (size_t k = 0; k < sigs.size(); ++k) if ((int)(sigs[k].first.size() / 12) == best_len) order.push_back((int)k);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sigs[(size_t)x].second > sigs[(size_t)y].second; });
+        int covered = 0;
+        std::vector<int> slot(sigs.size(), -1);
+        for (size_t k = 0; k < order.size() && npat < CS_NPAT; ++k) {
+          const auto& sgk = sigs[(size_t)order[k]];
+          if (sgk.second < 4) break;                          // a pattern must pay for its 96 bytes
+          slot[(size_t)order[k]] = npat;
+          plen[npat] = (int)(sgk.first.size() / 12);
+          for (int i = 0; i < plen[npat]; ++i) {
+            std::memcpy(&pdelta[npat][i], &sgk.first[(size_t)i * 12], 4);
+            std::memcpy(&pval[npat][i], &sgk.first[(size_t)i * 12 + 4], 8);
+          }
+          covered += sgk.second;
+          ++npat;
+        }
+        if (npat > 0 && 2 * covered >= nr) {
+          rowpat.assign(CS_ROWPAT_BYTES, 0xFF);
+          for (int t = 0; t < nr; ++t)
+            if (rowsig[(size_t)t] >= 0 && slot[(size_t)rowsig[(size_t)t]] >= 0) rowpat[(size_t)t] = (unsigned char)slot[(size_t)rowsig[(size_t)t]];
+          npatrows[b] = covered;
+          hdr_plen = best_len;
+        } else {
+          npat = 0;
+        }
+      }
+      const bool patterned = npat > 0;
+      // ---- the generic part: entries of the rows no pattern covers, with row offsets into it
+      gcol.clear(); gval.clear(); groff.assign((size_t)nr + 1, 0);
+      for (int t = 0; t < nr; ++t) {
+        groff[(size_t)t] = (unsigned short)gcol.size();
+        if (patterned && rowpat[(size_t)t] != 0xFF) continue;
+        for (int64_t q = rp[d.r0 + t]; q < rp[d.r0 + t + 1]; ++q) { gcol.push_back(ci[q]); gval.push_back(va[q]); }
+      }
+      groff[(size_t)nr] = (unsigned short)gcol.size();
+      const int ng = (int)gcol.size();
+      const size_t front = (size_t)CS_HDR + (patterned ? (size_t)CS_PAT_BYTES + CS_ROWPAT_BYTES : 0);
+      auto write_front = [&]() {
+        if (!patterned) return;
+        unsigned char* q = pk.data() + CS_HDR;
+        std::memcpy(q, pdelta, sizeof pdelta);
+        std::memcpy(q + sizeof pdelta, pval, sizeof pval);
+        std::memcpy(q + sizeof pdelta + sizeof pval, plen, sizeof plen);
+        std::memcpy(q + CS_PAT_BYTES, rowpat.data(), CS_ROWPAT_BYTES);
+        flags |= CS_PATTERNED;
       };
-      if (d.nnzb == 0) { roff_only(); continue; }
+      if (patterned && ng == 0) {                            // every row follows a pattern: no generic part at all
+        pk.assign(front, 0);
+        write_front();
+        finish(0);
+        continue;
+      }
+      // rows read from the CSR arrays in place (more bands / distinct values / bytes than the packed form takes):
+      // the record carries the row offsets of the CSR arrays themselves
+      auto csr_rows = [&]() {
+        pk.assign(front + CS_SEGS * 4 + (size_t)cs_roff_bytes(nr), 0);
+        write_front();
+        unsigned short* ro = reinterpret_cast<unsigned short*>(pk.data() + front + CS_SEGS * 4);
+        for (int r = 0; r <= nr; ++r) ro[r] = (unsigned short)(rp[d.r0 + r] - d.base);
+        flags |= CS_ROFF_ONLY | (patterned ? CS_HAS_GENERIC : 0);
+        nval = 0;
+        finish(d.nnzb);
+      };
+      if (ng == 0) { csr_rows(); continue; }                 // (an empty block: offsets only)
       // column bands: greedy cover of the sorted distinct columns with windows of 2^12
-      u.assign(ci + d.base, ci + d.base + d.nnzb);
+      u.assign(gcol.begin(), gcol.end());
       std::sort(u.begin(), u.end());
       u.erase(std::unique(u.begin(), u.end()), u.end());
       int32_t seg[CS_SEGS];
@@ -1553,37 +1845,39 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
         const int64_t lim = (int64_t)u[i] + (1 << CS_OFFBITS);
         while (i < u.size() && u[i] < lim) ++i;
       }
-      if (!ok) { roff_only(); continue; }
+      if (!ok) { csr_rows(); continue; }
       // distinct values by bit pattern
-      w.resize((size_t)d.nnzb);
-      std::memcpy(w.data(), va + d.base, sizeof(double) * (size_t)d.nnzb);
+      w.resize((size_t)ng);
+      std::memcpy(w.data(), gval.data(), sizeof(double) * (size_t)ng);
       std::sort(w.begin(), w.end());
       w.erase(std::unique(w.begin(), w.end()), w.end());
-      if (w.size() > (size_t)CS_MAXVAL) { roff_only(); continue; }
-      const int nval = (int)w.size(), nvpad = (nval + 1) & ~1;
-      const size_t ncode16 = ((size_t)d.nnzb + 7) >> 3, nid16 = ((size_t)d.nnzb + 15) >> 4;
-      const size_t nbytes = (size_t)cs_record_bytes(d.nnzb, nval, nr, false);
-      if (nbytes > (size_t)CSP_SLOT) { roff_only(); continue; }
+      if (w.size() > (size_t)CS_MAXVAL) { csr_rows(); continue; }
+      nval = (int)w.size();
+      const int nvpad = (nval + 1) & ~1;
+      const size_t ncode16 = ((size_t)ng + 7) >> 3, nid16 = ((size_t)ng + 15) >> 4;
+      const size_t nbytes = front + (size_t)cs_record_bytes(ng, nval, nr, false) - CS_HDR;
+      if (nbytes > (size_t)CSP_SLOT) { csr_rows(); continue; }
       pk.assign(nbytes, 0);
+      write_front();
+      if (patterned) flags |= CS_HAS_GENERIC;
+      unsigned char* g = pk.data() + front;
       int32_t segpad[CS_SEGS];
       for (int i = 0; i < CS_SEGS; ++i) segpad[i] = i < nseg ? seg[i] : 0;
-      std::memcpy(pk.data() + CS_HDR, segpad, sizeof segpad);
-      std::memcpy(pk.data() + CS_HDR + CS_SEGS * 4, w.data(), sizeof(uint64_t) * (size_t)nval);
-      unsigned short* code = reinterpret_cast<unsigned short*>(pk.data() + CS_HDR + CS_SEGS * 4 + (size_t)nvpad * 8);
-      unsigned char* vid = pk.data() + CS_HDR + CS_SEGS * 4 + (size_t)nvpad * 8 + ncode16 * 16;
+      std::memcpy(g, segpad, sizeof segpad);
+      std::memcpy(g + CS_SEGS * 4, w.data(), sizeof(uint64_t) * (size_t)nval);
+      unsigned short* code = reinterpret_cast<unsigned short*>(g + CS_SEGS * 4 + (size_t)nvpad * 8);
+      unsigned char* vid = g + CS_SEGS * 4 + (size_t)nvpad * 8 + ncode16 * 16;
       unsigned short* ro = reinterpret_cast<unsigned short*>(vid + nid16 * 16);
-      for (int q = 0; q < d.nnzb; ++q) {
-        const int32_t col = ci[d.base + q];
+      for (int q = 0; q < ng; ++q) {
+        const int32_t col = gcol[(size_t)q];
         const int sidx = (int)(std::upper_bound(seg, seg + nseg, col) - seg) - 1;
         code[q] = (unsigned short)((sidx << CS_OFFBITS) | (col - seg[sidx]));
         uint64_t bits;
-        std::memcpy(&bits, va + d.base + q, sizeof bits);
+        std::memcpy(&bits, &gval[(size_t)q], sizeof bits);
         vid[q] = (unsigned char)(std::lower_bound(w.begin(), w.end(), bits) - w.begin());
       }
-      for (int r = 0; r <= nr; ++r) ro[r] = (unsigned short)(rp[d.r0 + r] - d.base);
-      desc[b].nrnv |= nval << 16;
-      desc[b].soff = 0;   // final offset assigned below
-      header();
+      for (int r = 0; r <= nr; ++r) ro[r] = groff[(size_t)r];
+      finish(ng);
     }
   };
   unsigned nthreads = std::thread::hardware_concurrency();
@@ -1595,11 +1889,14 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
     pool.emplace_back(work, nb * i / nthreads, nb * (i + 1) / nthreads);
   for (auto& th : pool) th.join();
   size_t total = 0, nfall = 0;
+  int64_t patrows = 0;
   for (size_t b = 0; b < nb; ++b) {
     if (desc[b].nnzb > RgCfgA::NNZ_CAP || (desc[b].roff_only() && desc[b].nnzb > 0)) ++nfall;
     desc[b].soff = (long long)total;
     total += packs[b].size();
+    patrows += npatrows[b];
   }
+  a->cs_pattern_rows = patrows;
   std::vector<unsigned char> stream(total + 64, 0);      // (a dummy DMA piece of the loader reads bytes 0..16)
   for (size_t b = 0; b < nb; ++b)
     if (desc[b].soff >= 0) std::memcpy(stream.data() + desc[b].soff, packs[b].data(), packs[b].size());
@@ -1636,7 +1933,8 @@ extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const in
   mxg_ctx* c = a->ctx;
   MXG_HIP(hipSetDevice(c->device));
   if (a->pipe_geo != 10) MXG_TRY(build_pipe_desc(a, 10, rowptr));     // 16-bit row offsets of the same blocks
-  if (a->ncs == 0 && a->nrows > 0) {
+  const bool want_csp = csp_wanted();
+  if ((a->ncs == 0 || a->cs_patterned != (int)want_csp) && a->nrows > 0) {
     std::vector<int64_t> rp;
     std::vector<int32_t> ci;
     std::vector<double> va;
@@ -1650,11 +1948,14 @@ extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const in
       MXG_HIP(hipStreamSynchronize(c->stream));
       rowptr = rp.data(); colidx = ci.data(); vals = va.data();
     }
-    MXG_TRY(build_cs(a, rowptr, colidx, vals));
+    MXG_TRY(build_cs(a, rowptr, colidx, vals, want_csp));
+    a->cs_patterned = (int)want_csp;
+    // the pattern-dictionary product (mxg_pat.hip) for matrices without ghosts; MXG_PAT=0 keeps the record kernels
+    if (pat_wanted() && a->nghost == 0 && a->nneigh == 0 && !a->d_rowpid) MXG_TRY(mxg_pat_build(a, rowptr, colidx, vals));
   }
-  // 0x8000000: the persistent kernel with a loader wave (k_spmv_csp); MXG_CSP=0 keeps one block per workgroup
-  a->kernel = MXG_KERNEL_DEFAULT | 0x1000000;
-  { const char* e = getenv("MXG_CSP"); if (!e || atoi(e) != 0) a->kernel |= 0x8000000; }
+  // 0x8000000: the persistent kernel with a loader wave over patterned records (k_spmv_csp); MXG_CSP=0 at compress
+  // time builds the plain records and keeps one block per workgroup (k_spmv_cs)
+  a->kernel = MXG_KERNEL_DEFAULT | 0x1000000 | (want_csp ? 0x8000000 : 0) | ((pat_wanted() && a->d_rowpid) ? 0x10000000 : 0);
   if (nblocks) *nblocks = a->ncs;
   if (nfallback) *nfallback = a->cs_fallback;
   if (stream_bytes) *stream_bytes = a->cs_bytes;
@@ -1805,25 +2106,34 @@ static int launch_rowgather_halo(mxg_ctx* c, mxg_csr* a, const MvDesc& X, const 
   return 0;
 }
 
-// persistent compressed-stream kernel (no halo): D = 3 ring, six 320-thread workgroups per CU
-constexpr int CSP_DEPTH = 3;
+// persistent compressed-stream kernel: two records per iteration, a ring of two iterations (32 KiB of LDS), four
+// 320-thread workgroups per CU
+constexpr int CSP_DEPTH = 2, CSP_NB = 2;
 static inline bool csp_on(const mxg_csr* a) { return (a->kernel & 0x8000000) != 0; }
-template <bool DOT, int EPI>
-static void launch_csp(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const double* xdot, double* partial,
-                       const double* rhs, const double* diag, double omega, double beta) {
-  int wgs = 6;
+template <bool DOT, int EPI, bool HALO = false>
+static void launch_csp(mxg_ctx* c, mxg_csr* a, const CsDesc* desc, long long nblocks, const double* x, double* y,
+                       const double* xdot, double* partial, const double* rhs, const double* diag, double omega,
+                       double beta, const double* xg = nullptr, int nowned = 0) {
+  int wgs = 4;
   if (const char* e = getenv("MXG_CSP_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 8) wgs = v; }
-  const unsigned grid = (unsigned)std::max(MXG_NUM_XCD, (c->num_cu * wgs / MXG_NUM_XCD) * MXG_NUM_XCD);
-  int depth = CSP_DEPTH;
-  if (const char* e = getenv("MXG_CSP_DEPTH")) depth = atoi(e);
-  if (depth == 4 && !DOT && EPI == 0)        // tuning variant (plain product only)
-    hipLaunchKernelGGL((k_spmv_csp<7, false, 0, 4>), dim3(grid), dim3(CSP_THREADS), 0, c->stream,
-                       (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
-                       (const int*)a->d_colidx, (const double*)a->d_vals, x, y, xdot, partial, rhs, diag, omega, beta);
-  else
-  hipLaunchKernelGGL((k_spmv_csp<7, DOT, EPI, CSP_DEPTH>), dim3(grid), dim3(CSP_THREADS), 0, c->stream,
-                     (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
-                     (const int*)a->d_colidx, (const double*)a->d_vals, x, y, xdot, partial, rhs, diag, omega, beta);
+  long long grid = std::max(MXG_NUM_XCD, (c->num_cu * wgs / MXG_NUM_XCD) * MXG_NUM_XCD);
+  const long long per = (nblocks + MXG_NUM_XCD - 1) / MXG_NUM_XCD;           // blocks per XCD
+  grid = std::min(grid, ((per + CSP_NB - 1) / CSP_NB) * MXG_NUM_XCD);        // small matrices: one group per workgroup
+  static const bool stamps = getenv("MXG_CSP_STAMPS") != nullptr;
+  if (stamps && !DOT && EPI == 0 && !HALO) {
+    hipLaunchKernelGGL((k_spmv_csp<7, false, 0, CSP_DEPTH, false, CSP_NB, true>), dim3((unsigned)grid), dim3(CSP_THREADS), 0, c->stream,
+                       desc, nblocks, (const unsigned char*)a->d_csstream, (const int*)a->d_colidx,
+                       (const double*)a->d_vals, x, y, xdot, partial, rhs, diag, omega, beta, xg, nowned);
+    unsigned long long h[16];
+    hipStreamSynchronize(c->stream);
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_csp_stamps), sizeof h) == hipSuccess)
+      fprintf(stderr, "[csp stamps] loader: wait %llu barrier %llu issue %llu cycles over %llu iterations; consumer: barrier %llu gather-issue %llu gather-wait %llu finish %llu\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    return;
+  }
+  hipLaunchKernelGGL((k_spmv_csp<7, DOT, EPI, CSP_DEPTH, HALO, CSP_NB>), dim3((unsigned)grid), dim3(CSP_THREADS), 0, c->stream,
+                     desc, nblocks, (const unsigned char*)a->d_csstream, (const int*)a->d_colidx,
+                     (const double*)a->d_vals, x, y, xdot, partial, rhs, diag, omega, beta, xg, nowned);
 }
 
 // compressed-stream kernel on a row-partitioned matrix (real, one column): interior blocks, wait for the halo,
@@ -1833,6 +2143,15 @@ static int launch_cs_halo(mxg_ctx* c, mxg_csr* a, const double* x, double* y, co
                           const double* rhs, const double* diag, double omega, double beta = 0.0) {
   const CsDesc* desc = (const CsDesc*)a->d_csdesc;
   const long long ni = a->ncs_interior, nb = a->ncs - a->ncs_interior;
+  if (csp_on(a)) {
+    // persistent kernel: the blocks that reference no ghost column run while the halo is in flight
+    if (ni > 0) launch_csp<DOT, EPI, false>(c, a, desc, ni, x, y, xdot, partial, rhs, diag, omega, beta);
+    MXG_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    if (nb > 0) launch_csp<DOT, EPI, true>(c, a, desc + ni, nb, x, y, xdot, DOT ? partial + ni : partial, rhs, diag, omega, beta,
+                                            (const double*)a->d_ghost, (int)a->ncols_owned);
+    MXG_HIP(hipGetLastError());
+    return 0;
+  }
   if (ni > 0) {
     const unsigned grid = (unsigned)(((ni + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
     hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, DOT, EPI, false>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream, desc, ni,
@@ -1905,8 +2224,10 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
     const long long per = (a->ncs + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
     for (int j = 0; j < X.k; ++j)
-      if (csp_on(a))
-        launch_csp<false, 0>(c, a, (const double*)X.col(j), Y.col(j), nullptr, nullptr, nullptr, nullptr, 0.0, 0.0);
+      if (pat_on(a)) {
+        if (mxg_pat_launch(c, a, (const double*)X.col(j), Y.col(j), 0, 0, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0, nullptr)) return 1;
+      } else if (csp_on(a))
+        launch_csp<false, 0>(c, a, (const CsDesc*)a->d_csdesc, a->ncs, (const double*)X.col(j), Y.col(j), nullptr, nullptr, nullptr, nullptr, 0.0, 0.0);
       else
       hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, false>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
                          (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,
@@ -2031,15 +2352,19 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
                      (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,        \
                      (const unsigned short*)a->d_roff, a->d_colidx, a->d_vals, (const double*)X.col(0), Y.col(0), \
                      (const double*)nullptr, (double*)nullptr, rhs, diag, omega, (const double*)nullptr, 0LL, beta)
+  if (pat_on(a)) {
+    if (mxg_pat_launch(c, a, (const double*)X.col(0), Y.col(0), epi, 0, nullptr, nullptr, rhs, diag, omega, beta, 0, nullptr)) return 2;
+    return 0;
+  }
   if (csp_on(a)) {
     const double* xp = X.col(0);
     double* yp = Y.col(0);
-    if (epi == 1) launch_csp<false, 1>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
-    else if (epi == 2) launch_csp<false, 2>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
-    else if (epi == 3) launch_csp<false, 3>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
-    else if (epi == 4) launch_csp<false, 4>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
-    else if (epi == 5) launch_csp<false, 5>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
-    else launch_csp<false, 0>(c, a, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    if (epi == 1) launch_csp<false, 1>(c, a, (const CsDesc*)a->d_csdesc, a->ncs, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 2) launch_csp<false, 2>(c, a, (const CsDesc*)a->d_csdesc, a->ncs, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 3) launch_csp<false, 3>(c, a, (const CsDesc*)a->d_csdesc, a->ncs, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 4) launch_csp<false, 4>(c, a, (const CsDesc*)a->d_csdesc, a->ncs, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else if (epi == 5) launch_csp<false, 5>(c, a, (const CsDesc*)a->d_csdesc, a->ncs, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
+    else launch_csp<false, 0>(c, a, (const CsDesc*)a->d_csdesc, a->ncs, xp, yp, nullptr, nullptr, rhs, diag, omega, beta);
   } else
   if (epi == 1) MXG_CS_EPI(1); else if (epi == 2) MXG_CS_EPI(2); else if (epi == 3) MXG_CS_EPI(3); else if (epi == 4) MXG_CS_EPI(4);
   else if (epi == 5) MXG_CS_EPI(5); else MXG_CS_EPI(0);
@@ -2061,7 +2386,11 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
   }
   MvDesc X = x->desc();
   const MvDesc Y = y->desc();
-  if (!a->d_dotpartial) MXG_HIP(hipMalloc(&a->d_dotpartial, sizeof(double) * a->npipe));
+  if (!a->d_dotpartial || a->dotpartial_cap < a->npipe) {
+    if (a->d_dotpartial) hipFree(a->d_dotpartial);
+    MXG_HIP(hipMalloc(&a->d_dotpartial, sizeof(double) * a->npipe));
+    a->dotpartial_cap = a->npipe;
+  }
   if (a->nghost > 0 || a->nneigh > 0) {
     MXG_TRY(halo_start(c, a, x));
     (void)hipGetLastError();
@@ -2078,8 +2407,20 @@ int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, do
   const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
   const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
   (void)hipGetLastError();
+  if ((a->kernel & 0x1000000) && pat_on(a)) {
+    const int64_t np = mxg_pat_partials(a);
+    if (a->dotpartial_cap < np) {
+      if (a->d_dotpartial) hipFree(a->d_dotpartial);
+      MXG_HIP(hipMalloc(&a->d_dotpartial, sizeof(double) * np));
+      a->dotpartial_cap = np;
+    }
+    if (mxg_pat_launch(c, a, (const double*)X.col(0), Y.col(0), 0, 1, (const double*)x->colptr(0), a->d_dotpartial, nullptr, nullptr, 0.0, 0.0, 0, nullptr)) return 1;
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, (const double*)a->d_dotpartial, (long long)np, d_out);
+    MXG_HIP(hipGetLastError());
+    return 0;
+  }
   if ((a->kernel & 0x1000000) && a->ncs == a->npipe && csp_on(a))
-    launch_csp<true, 0>(c, a, (const double*)X.col(0), Y.col(0), (const double*)x->colptr(0), a->d_dotpartial, nullptr, nullptr, 0.0, 0.0);
+    launch_csp<true, 0>(c, a, (const CsDesc*)a->d_csdesc, a->ncs, (const double*)X.col(0), Y.col(0), (const double*)x->colptr(0), a->d_dotpartial, nullptr, nullptr, 0.0, 0.0);
   else if ((a->kernel & 0x1000000) && a->ncs == a->npipe)
     hipLaunchKernelGGL((k_spmv_cs<RgCfgA, 7, true>), dim3(grid), dim3(RgCfgA::SBLK / CS_RPT), 0, c->stream,
                        (const CsDesc*)a->d_csdesc, (long long)a->ncs, (const unsigned char*)a->d_csstream,

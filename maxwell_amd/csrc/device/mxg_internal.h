@@ -130,12 +130,20 @@ struct mxg_csr {
   int64_t npipe = 0;
   int pipe_geo = -1;
   double* d_dotpartial = nullptr;   // per-block partials of the fused SpMV + dot
+  int64_t dotpartial_cap = 0;
   unsigned short* d_roff = nullptr; // row-gather kernel: 16-bit in-block row offsets (nrows + nblocks + 1)
   unsigned short* d_roff16 = nullptr; // persistent row-gather kernel: the same, 264 entries per block (16-byte aligned pieces)
   // compressed-stream kernel (mxg_csr_compress): 32-byte block descriptors + packed per-block streams
   void* d_csdesc = nullptr;
   unsigned char* d_csstream = nullptr;
   int64_t ncs = 0, cs_fallback = 0, cs_bytes = 0;
+  int cs_patterned = -1;         // records built with (1) / without (0) pattern tables
+  // pattern-dictionary product (mxg_pat.hip): per-row dictionary ids, the dictionary, the individual rows
+  unsigned short* d_rowpid = nullptr;
+  void* d_patdict = nullptr;
+  int32_t* d_grows = nullptr;
+  int64_t pat_npat = 0, pat_ngrows = 0, pat_gnnz = 0;
+  int64_t cs_pattern_rows = 0;   // rows encoded as one pattern id (persistent kernel's records)
   int64_t ncs_interior = 0;      // compressed descriptors [0, ncs_interior) reference no ghost column
   // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
   void* d_xwdesc = nullptr;
@@ -185,6 +193,13 @@ int mxg_dev_dot(mxg_ctx* ctx, const MvDesc& A, const MvDesc& B, double* d_out);
 int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
                           const double* diag, double omega, double beta = 0.0);
 int mxg_dev_csr_apply_dot(mxg_ctx* ctx, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out);
+
+// pattern-dictionary product (mxg_pat.hip)
+int mxg_pat_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
+int64_t mxg_pat_partials(const mxg_csr* a);
+int mxg_pat_launch(mxg_ctx* c, mxg_csr* a, const double* x, double* y, int epi, int dot, const double* xdot,
+                   double* partial, const double* rhs, const double* diag, double omega, double beta, int halo,
+                   const double* xg);
 
 inline int mxg_grid_for(int64_t n, int block, int per_thread, int cap) {
   int64_t g = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);

@@ -35,7 +35,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     if not f:
         continue
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
-    vals = [float(r["Counter_Value"]) for r in rows if "k_spmv_rowgather" in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in rows if "k_spmv_rgp" in r["Kernel_Name"] or "k_spmv_rowgather" in r["Kernel_Name"]]
     res[ctr] = {"dispatches": len(vals), "mean_raw_KiB": sum(vals) / max(len(vals), 1)}
     vcs = [float(r["Counter_Value"]) for r in rows if "k_spmv_cs" in r["Kernel_Name"]]
     if vcs:

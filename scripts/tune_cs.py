@@ -7,7 +7,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ctx = mx.Ctx(0)
 sim = mx.Sim.pillbox(n)
 out = []
+only = sys.argv[2] if len(sys.argv) > 2 else None
 for name, shift in (("vecLapl", 0.05 * (2 * np.pi) ** 2), ("scaLapl", None)):
+    if only and name != only:
+        continue
     A = sim.to_device(ctx, name, shift=shift)
     X = mx.MultiVec(ctx, A.ncols, 1); Y = mx.MultiVec(ctx, A.nrows, 1); Z = mx.MultiVec(ctx, A.nrows, 1); X.random(1)
     alg = A.apply_bytes(1)
@@ -18,17 +21,20 @@ for name, shift in (("vecLapl", 0.05 * (2 * np.pi) ** 2), ("scaLapl", None)):
         return ctx.timer_stop() / 100
     ms0 = timed()
     A.apply(X, Z)
-    t0 = time.time(); nb, nf, nbytes = A.compress(); tc = time.time() - t0
+    t0 = time.time(); nb, nf, nbytes = A.compress(); tc = time.time() - t0       # default: pattern dictionary
     ms1 = timed()
     same = bool(np.array_equal(Y.to_numpy(), Z.to_numpy()))
-    # the one-block-per-workgroup kernel on the same records (MXG_CSP=0 at compress time clears the persistent bit)
-    os.environ["MXG_CSP"] = "0"; A.compress(); ms_old = timed(); same = same and bool(np.array_equal(Y.to_numpy(), Z.to_numpy()))
-    os.environ.pop("MXG_CSP")
-    cs_bytes = nbytes + 16 * A.nrows                       # packed records (incl. row offsets) + x + y
-    rec = dict(op=name, rows=A.nrows, nnz=A.nnz, csr_ms=round(ms0, 4), cs_ms=round(ms1, 4), speedup=round(ms0 / ms1, 3),
-               cs_one_block_per_wg_ms=round(ms_old, 4), cs_own_bytes=cs_bytes, cs_own_GBps=round(cs_bytes / ms1 / 1e6, 1),
-               cs_frac_of_8TBps=round(cs_bytes / ms1 / 1e6 / 8000.0, 3),
-               csr_GBps=round(alg / ms0 / 1e6, 1), cs_effective_GBps=round(alg / ms1 / 1e6, 1), blocks=nb, fallback_blocks=nf,
+    other = {}
+    for mode, (pat, csp) in (("cs_one_record_per_wg", ("0", "0")), ("csp_persistent_loader", ("0", "1"))):
+        os.environ["MXG_PAT"] = pat; os.environ["MXG_CSP"] = csp
+        A.compress(); other[mode + "_ms"] = round(timed(), 4)
+        same = same and bool(np.array_equal(Y.to_numpy(), Z.to_numpy()))
+    os.environ.pop("MXG_PAT"); os.environ.pop("MXG_CSP")
+    pat_bytes = 2 * A.nrows + 16 * A.nrows                      # row ids + x + y (dictionary and individual rows are noise)
+    rec = dict(op=name, rows=A.nrows, nnz=A.nnz, csr_ms=round(ms0, 4), pat_ms=round(ms1, 4), speedup=round(ms0 / ms1, 3),
+               pat_own_bytes=pat_bytes, pat_own_GBps=round(pat_bytes / ms1 / 1e6, 1), pat_frac_of_8TBps=round(pat_bytes / ms1 / 8e9, 3),
+               **other,
+               csr_GBps=round(alg / ms0 / 1e6, 1), pat_effective_GBps=round(alg / ms1 / 1e6, 1), blocks=nb, fallback_blocks=nf,
                packed_stream_bytes=nbytes, csr_matrix_bytes=A.nnz * 12, compress_seconds=round(tc, 2), bit_identical=same)
     print(json.dumps(rec), flush=True)
     out.append(rec)

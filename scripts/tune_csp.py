@@ -15,8 +15,7 @@ def timed():
     ctx.sync(); ctx.timer_start()
     for _ in range(50): A.apply(X, Y)
     return ctx.timer_stop() / 50
-for depth in (3, 4):
-    for wgs in (1, 2, 3, 4, 5, 6):
-        os.environ["MXG_CSP_DEPTH"] = str(depth); os.environ["MXG_CSP_WGS"] = str(wgs)
-        ms = timed()
-        print("depth %d wgs/CU %d: %.4f ms  %.0f GB/s own bytes (%.3f of 8 TB/s)" % (depth, wgs, ms, own / ms / 1e6, own / ms / 8e9), flush=True)
+for wgs in (1, 2, 3, 4, 5):
+    os.environ["MXG_CSP_WGS"] = str(wgs)
+    ms = timed()
+    print("wgs/CU %d: %.4f ms  %.0f GB/s own bytes (%.3f of 8 TB/s)" % (wgs, ms, own / ms / 1e6, own / ms / 8e9), flush=True)

@@ -322,13 +322,17 @@ def test_config3_cylinder_and_config5_sphere_geometries(ctx, rng):
             assert np.array_equal(Y.to_numpy(), cref.spmv(host, x))
 
 
-@pytest.mark.parametrize("csp", ["1", "0"])
-def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, csp, monkeypatch):
+CS_MODES = {"pat": ("1", "0"), "cs": ("0", "0"), "csp": ("0", "1")}     # (MXG_PAT, MXG_CSP) at compress time
+
+
+@pytest.mark.parametrize("mode", list(CS_MODES))
+def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, mode, monkeypatch):
     """mxg_csr_compress: 16-bit band codes + 8-bit value-table indices per row block; every operator of
     the pillbox (bulk blocks pack, cut-cell blocks fall back to plain CSR rows), SpMV and SpMM, and the
-    fused SpMV+dot of CG give the same bits as the serial row loop.  csp = 1: the persistent kernel with a
-    loader wave (k_spmv_csp, the default); 0: one block per workgroup (k_spmv_cs)."""
-    monkeypatch.setenv("MXG_CSP", csp)
+    fused SpMV+dot of CG give the same bits as the serial row loop.  Modes: "pat" the pattern-dictionary product
+    (k_spmv_pat + k_spmv_gen), "cs" one record per workgroup (k_spmv_cs, the default), "csp" the persistent record
+    kernel with a loader wave (k_spmv_csp)."""
+    monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0]); monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
     _, o = oracle_pillbox16
     packed_any = False
     for name in ("vecLapl", "scaLapl", "curlCurl", "curlE", "divB", "gradPsi", "mRhs"):
@@ -362,10 +366,10 @@ def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, csp, monkey
     assert np.abs(sols[0][1] - sols[1][1]).max() <= 1e-8 * np.abs(sols[0][1]).max()
 
 
-@pytest.mark.parametrize("csp", ["1", "0"])
-def test_compressed_stream_fallbacks(ctx, rng, csp, monkeypatch):
+@pytest.mark.parametrize("mode", list(CS_MODES))
+def test_compressed_stream_fallbacks(ctx, rng, mode, monkeypatch):
     """Blocks with more than 16 column bands or 256 distinct values, empty rows and an over-long row."""
-    monkeypatch.setenv("MXG_CSP", csp)
+    monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0]); monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
     n = 9000
     rows = [rng.choice(n, size=int(c), replace=False) for c in rng.integers(0, 12, size=n)]   # scattered columns
     rows[5] = np.arange(n)[:2600]                        # longer than a block
