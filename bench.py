@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--eig-n", type=int, default=256, help="grid of the eigenpairs/s measurement (0 = skip)")
     p.add_argument("--eig-timeout", type=int, default=420, help="N > 1: seconds the decomposed eigen-solve may take")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
+    p.add_argument("--cpu-eig-n", type=int, default=28, help="grid of the CPU eigenpairs/s sample (sparse direct shift-invert)")
     p.add_argument("--no-compressed", action="store_true", help="skip the compressed-stream side measurement")
     p.add_argument("--dist-selftest", action="store_true",
                    help="run the N > 1 code path (torch.distributed + RCCL ctx + box assembly + halo plan) on 1 rank")
@@ -71,8 +72,63 @@ def cpu_baseline(sim, shift, nrows, alg_bytes, budget):
             "serial_value": round(alg_bytes / serial / 1e9, 3)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU, the
+    environment torch.distributed.run would give them), before anything in this process touches the GPU; relay rank
+    0's JSON line; exit with the worst child status."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    host_threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   OMP_NUM_THREADS=str(max(1, min(32, host_threads // n))))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        log("rank exit codes: %s" % rcs)
+    sys.exit(max(abs(rc) for rc in rcs) if any(rcs) else 0)
+
+
+def cpu_eigen_baseline(n):
+    """eigenpairs/s of the CPU path on a bounded sample: the oracle-side solve (scipy's ARPACK shift-invert with a sparse
+    LU of L - sigma M: what tests/test_eigen_gpu.py checks the GPU eigenvalues against) of the same pillbox pencil at n^3
+    cells, nev 5, on the host cores of this box.  256^3 is out of reach of a sparse direct factorisation (fill-in), so the
+    size is stated; the GPU figure beside it is for 256^3."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import maxwell_amd as mx
+    sim = mx.Sim.pillbox(n)
+    shift = 0.05 * (2.0 * np.pi) ** 2
+    L, M, D = sim.op("vecLapl"), sim.op("mRhs"), sim.op("divB")
+    keep = (sim.used_mask() != 0) & (M.diagonal() > 0)
+    t0 = time.perf_counter()
+    vals, vecs = spla.eigsh(L[keep][:, keep].tocsc(), k=12, M=sp.diags(M.diagonal()[keep]).tocsc(), sigma=shift, which="LM", tol=1e-8)
+    secs = time.perf_counter() - t0
+    phys = 0
+    for lam, v in zip(vals, vecs.T):
+        full = np.zeros(L.shape[0]); full[keep] = v
+        if np.linalg.norm(D @ (M @ full)) / np.linalg.norm(full) < 1e-6:
+            phys += 1
+    sim.close()
+    return {"value": round(min(phys, 5) / secs, 4), "unit": "eigenpairs/s", "kind": "port",
+            "sample": "pillbox %d^3 (%d rows), 5 physical pairs of 12 computed, scipy ARPACK shift-invert + SuperLU, tol 1e-8, "
+                      "%.1f s; the GPU `eigen` figure is for 256^3" % (n, int(keep.sum()), secs)}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.dist_selftest:
+        spawn_ranks(args)
     # stdout carries exactly one line, the JSON: native libraries print banners and progress to fd 1 (RCCL's version
     # block, gloo's rendezvous note, the solver's tables), so fd 1 points at stderr until that line is written
     sys.stdout.flush()
@@ -82,7 +138,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log("WARNING: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+        log("ERROR: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+        sys.exit(2)
     if world > 1 or args.dist_selftest:
         # torch bundles its own ROCm runtime libraries with the same SONAMEs as /opt/rocm's: whichever
         # is loaded first serves the whole process.  Import torch BEFORE libmxg so that both run on one
@@ -115,6 +172,10 @@ def main():
     if os.environ.get("MXG_SHARE_GPU"):        # rehearsal of N ranks on a 1-GPU box (RCCL may refuse duplicates)
         local = 0
     ctx = mx.Ctx(local, rank, world, uid)
+    nccl_ranks_seen = ctx.comm_ranks()         # ncclCommCount of the communicator the data path uses
+    if world > 1 and nccl_ranks_seen != world:
+        log("ERROR: RCCL reports %d ranks, launched %d" % (nccl_ranks_seen, world))
+        sys.exit(4)
 
     shift = 0.05 * (2.0 * np.pi) ** 2          # src/mx.py:711-712 default for the unit box
     t0 = time.perf_counter()
@@ -165,7 +226,7 @@ def main():
         "metric": "MxMagWaveOp SpMV achieved HBM GB/s (eigenpairs/s in `eigen`)",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "nccl_ranks_seen": nccl_ranks_seen,
         "config": {"workload": workload, "rows": rows, "nnz": nnz, "block_vectors": args.k,
                    "parallelism": parallelism, "index_types": "int64 rowptr, int32 colidx",
                    "setup_seconds": round(setup_s, 2)},
@@ -192,6 +253,10 @@ def main():
         pass
     if rank == 0 and args.cpu_seconds > 0 and world == 1 and not args.dist_selftest:
         out["cpu_baseline"] = cpu_baseline(sim, shift, A.nrows, alg, args.cpu_seconds)
+        try:
+            out["cpu_baseline"]["eigen"] = cpu_eigen_baseline(args.cpu_eig_n)
+        except Exception as e:
+            out["cpu_baseline"]["eigen"] = {"error": str(e)}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0 and world == 1 and not args.dist_selftest and args.kernel < 0 and not args.no_compressed:
@@ -231,10 +296,11 @@ def main():
         import threading
 
         def bail():
+            # a rank stopped answering: the SpMV line still goes out (with the error in it), the status says failure
             if rank == 0:
                 out["eigen"] = {"error": "decomposed eigen-solve did not finish within %d s" % args.eig_timeout}
                 os.write(json_fd, (json.dumps(out) + "\n").encode())
-            os._exit(0)
+            os._exit(3)
 
         try:
             sim.close()          # the window operators of the SpMV workload (host memory) are not needed any more

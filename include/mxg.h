@@ -48,6 +48,8 @@ int mxg_ctx_destroy(mxg_ctx* ctx);
 int mxg_ctx_sync(mxg_ctx* ctx);
 int mxg_ctx_rank(const mxg_ctx* ctx);
 int mxg_ctx_nranks(const mxg_ctx* ctx);
+/* ranks the RCCL communicator reports (ncclCommCount); 1 when there is none, -1 on error */
+int mxg_ctx_comm_ranks(const mxg_ctx* ctx);
 /* HIP-event timer on the ctx stream (the stream every kernel of this ctx is launched on) */
 int mxg_timer_start(mxg_ctx* ctx);
 int mxg_timer_stop(mxg_ctx* ctx, float* elapsed_ms);

@@ -48,6 +48,7 @@ MXG_SIGNATURES = {
     "mxg_ctx_sync": (C.c_int, [vp]),
     "mxg_ctx_rank": (C.c_int, [vp]),
     "mxg_ctx_nranks": (C.c_int, [vp]),
+    "mxg_ctx_comm_ranks": (C.c_int, [vp]),
     "mxg_timer_start": (C.c_int, [vp]),
     "mxg_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "mxg_barrier": (C.c_int, [vp]),

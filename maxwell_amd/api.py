@@ -95,6 +95,10 @@ class Ctx:
         _chk(lib.mxg_get_unique_id(C.cast(buf, C.c_void_p)), lib)
         return bytes(buf)
 
+    def comm_ranks(self):
+        """Ranks RCCL itself reports for this context's communicator (ncclCommCount); 1 without one."""
+        return int(self.lib.mxg_ctx_comm_ranks(self.h))
+
     def sync(self):
         _chk(self.lib.mxg_ctx_sync(self.h), self.lib)
 

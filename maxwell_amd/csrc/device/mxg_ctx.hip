@@ -103,6 +103,15 @@ extern "C" int mxg_ctx_sync(mxg_ctx* c) {
 extern "C" int mxg_ctx_rank(const mxg_ctx* c) { return c->rank; }
 extern "C" int mxg_ctx_nranks(const mxg_ctx* c) { return c->nranks; }
 
+// ranks the RCCL communicator itself reports (ncclCommCount); 1 without a communicator, -1 on error:
+// lets a launcher verify that RCCL really connected as many ranks as it started
+extern "C" int mxg_ctx_comm_ranks(const mxg_ctx* c) {
+  if (!c->comm) return c->lw ? c->nranks : 1;
+  int n = -1;
+  if (ncclCommCount(c->comm, &n) != ncclSuccess) return -1;
+  return n;
+}
+
 extern "C" int mxg_timer_start(mxg_ctx* c) {
   MXG_HIP(hipEventRecord(c->ev0, c->stream));
   return 0;
