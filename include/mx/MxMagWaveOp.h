@@ -285,9 +285,16 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
       if (pid == 0 && verbose) std::cout << "Using CG/GMRES with aggregation multigrid preconditioner (GPU).\n";
       mOpts.precond = 3;
       mUseMg = true;
-    } else if (precType == "ilu" || precType == "jacobi") {
-      // AztecOO's ILUT is a Trilinos package; the SpMV-only stand-in is diagonal scaling
-      if (pid == 0 && verbose) std::cout << "MxMagWaveOp: '" << precType << "' preconditioner -> Jacobi (GPU, SpMV-only).\n";
+    } else if (precType == "ilu") {
+      // AztecOO's ILUT (src/MxMagWaveOp.cpp:365-383; the preconditioner example/pillbox.py asks for) is a Trilinos
+      // package and a sequential triangular solve.  Its place is taken by the strong preconditioner this library has,
+      // the aggregation multigrid: diagonal scaling would need ~60x the inner iterations at 256^3 (1984 instead of 31,
+      // profiles/r01b/multigrid_vs_jacobi_256.txt).  One line says so; `type = jacobi` selects diagonal scaling.
+      if (pid == 0) std::cout << "MxMagWaveOp: preconditioner 'ilu' (AztecOO ILUT) is served by the aggregation multigrid (GPU, SpMV-only).\n";
+      mOpts.precond = 3;
+      mUseMg = true;
+    } else if (precType == "jacobi") {
+      if (pid == 0 && verbose) std::cout << "MxMagWaveOp: 'jacobi' preconditioner: diagonal scaling (GPU).\n";
       mOpts.precond = 1;
     } else if (precType == "none") {
       if (pid == 0 && verbose) std::cout << "MxMagWaveOp: WARNING: no preconditioner!\n";

@@ -539,6 +539,9 @@ class MxProblem {
       } else if (type == "ilu") {
         if (pid == 0) std::cout << "  Found ILU preconditioner\n";
         for (int i = 0; i < 2; ++i) addParam(prec, "linear solver : ilu : ", iluParams()[i]);
+      } else if (type == "jacobi") {
+        // extension of the reference's grammar (amg | ilu): plain diagonal scaling, no parameters
+        if (pid == 0) std::cout << "  Found Jacobi (diagonal scaling) preconditioner\n";
       } else {
         std::ostringstream os;
         os << "Did not understand Preconditioner type: '" << type << "'.\n\nOffending XML block:\n" << prec;

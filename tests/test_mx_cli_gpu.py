@@ -102,6 +102,33 @@ def test_maxwell_cli_pillbox_deck(built, tmp_path):
             assert np.abs(arr).max() > 0 and np.all(arr[0, 0, :, :] == 0.0)     # metal corner column: not in the map
 
 
+def test_reference_writer_layout_deck(built, ctx, tmp_path):
+    """tests/golden/pillbox_mxpy.mx is config 1 (example/pillbox.py at 32^3, nev 5, basis 100, GMRES(40) + ILU) laid
+    out the way the reference's writer does it - hand-derived from src/mx.py:48-55 (attributes, then children),
+    :468-511 (BC lists spelled `[ periodic, periodic, periodic]`, the always-present <Output> block), :577-648 (solver
+    blocks), :694-716 (root <Maxwell>, `domain`, the default shift as Python prints it); the reference's Python is not
+    run.  Through `maxwell --infile=` and through the C ABI; `ilu` is served by the multigrid:
+    <= 60 inner iterations per Apply."""
+    name = os.path.join(GOLDEN, "pillbox_mxpy.mx")
+    deck = mxdeck.load(name)
+    assert deck.params["eigensolver : shift"] == 1.9739208802178716 and deck.params["linear solver : prec type"] == "ilu"
+    solver = mx.Problem(path=name).solver(ctx)
+    assert solver.solve() == 5
+    st = solver.stats()
+    assert st["vec_iters"] <= 60 * st["applies"] and st["sca_iters"] <= 60 * st["applies"], st
+    k2 = np.sort([solver.result(i)["k2"].real for i in range(5)])
+    tm010 = (2.404825557695773 / 0.4) ** 2
+    te111 = (1.8411837813406593 / 0.4) ** 2 + (np.pi / 0.8) ** 2
+    assert abs(k2[0] - tm010) / tm010 < 2e-3 and abs(k2[1] - te111) / te111 < 2e-3 and abs(k2[2] - te111) / te111 < 2e-3
+    r = subprocess.run([CLI, "--infile=" + name, "--no-fields"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "served by the aggregation multigrid" in r.stdout
+    rows = re.findall(r"^\s*(\d+):\s+(\S+)\s+(\S+)\s+(\S+)\s*$", r.stdout, flags=re.M)
+    assert len(rows) == 5
+    f = np.sort([float(row[1]) for row in rows])
+    assert np.allclose((2 * np.pi * f / C0) ** 2, k2, rtol=1e-4)
+
+
 def test_maxwell_cli_errors(built, tmp_path):
     r = subprocess.run([CLI], capture_output=True, text=True, timeout=60)
     assert "Please specify an input file using --infile=your_file.mx" in r.stdout
@@ -252,12 +279,14 @@ def test_multigrid_of_the_real_part_preconditions_complex_solves(ctx):
     for text, strict, want in ((lossy, True, 3), (bloch, False, 4)):
         assert ("type = amg" in text) != ("type = ilu" in text)
         res = {}
-        for prec in ("amg", "ilu"):
+        for prec in ("amg", "jacobi", "ilu"):       # `ilu` is served by the multigrid (include/mx/MxMagWaveOp.h)
             t = text.replace("type = amg", "type = " + prec).replace("type = ilu", "type = " + prec)
             solver = mx.Problem(text=t, strict=strict).solver(ctx)
             assert solver.solve() == want
             res[prec] = (np.array(sorted((solver.result(i)["k2"] for i in range(want)), key=lambda z: (round(z.real, 6), z.imag))),
                          solver.stats())
         tol = 50 * float(mx.Problem(text=text, strict=strict).param("eigensolver : tol"))
-        assert np.abs(res["amg"][0] - res["ilu"][0]).max() / np.abs(res["ilu"][0]).max() < tol
-        assert res["amg"][1]["vec_iters"] < 0.5 * res["ilu"][1]["vec_iters"], (res["amg"][1], res["ilu"][1])
+        assert np.abs(res["amg"][0] - res["jacobi"][0]).max() / np.abs(res["jacobi"][0]).max() < tol
+        assert np.abs(res["ilu"][0] - res["jacobi"][0]).max() / np.abs(res["jacobi"][0]).max() < tol
+        assert res["amg"][1]["vec_iters"] < 0.5 * res["jacobi"][1]["vec_iters"], (res["amg"][1], res["jacobi"][1])
+        assert res["ilu"][1]["vec_iters"] < 0.5 * res["jacobi"][1]["vec_iters"], (res["ilu"][1], res["jacobi"][1])

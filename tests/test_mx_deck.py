@@ -14,7 +14,7 @@ from oracle import mxdeck
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 pytestmark = pytest.mark.usefixtures("built")
-DECKS = ["pillbox.mx", "vacuum.mx", "tilted_cavity.mx", "dsphmsph.mx", "crabcell.mx"]
+DECKS = ["pillbox.mx", "pillbox_mxpy.mx", "vacuum.mx", "tilted_cavity.mx", "dsphmsph.mx", "crabcell.mx"]
 COMPLEX_DECKS = ["fiber.mx", "pillwtubes.mx"]
 
 
