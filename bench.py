@@ -232,7 +232,7 @@ def main():
                    "setup_seconds": round(setup_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "k_spmv_rgp<7,2> (persistent, LDS-DMA double-buffered row-gather; 16-bit in-block row offsets)" if args.kernel < 0 else "variant %#x" % args.kernel,
+                     "kernel": "k_spmv_rowgather<RgCfg<256,2048>,7> (16-bit in-block row offsets, branch-free row walk)" if args.kernel < 0 else "variant %#x" % args.kernel,
                      "kernel_ms": round(kern_ms, 5),
                      "algorithmic_bytes_per_launch": alg // world,
                      "note": "achieved = nnz*12 + rows*(8+8k) + cols*8k bytes (SURVEY 8d CSR formula) / HIP-event time per "

@@ -487,7 +487,7 @@ typedef RgCfg<256, 3072> RgCfgB;   // rows up to 12 nnz stay at 256 rows per blo
 // CG fused into the product; one value per block, combined in block order by k_sum_partials)
 // HALO: columns >= nowned are ghosts and live in a separate buffer (column j at xghost + j * ldghost): the
 // owned part of x is read in place, no [owned | ghosts] copy is assembled.
-template <typename CFG, int CH, bool DOT = false, bool HALO = false>
+template <typename CFG, int CH, bool DOT = false, bool HALO = false, int KT = 1>
 __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
     const BlkDesc* __restrict__ desc, long long nblocks, const long long* __restrict__ rowptr,
     const int* __restrict__ colidx, const double* __restrict__ vals, MvDesc X, MvDesc Y,
@@ -549,13 +549,22 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
     }
   }
   __syncthreads();
-  for (int j = 0; j < X.k; ++j) {
-    const double* __restrict__ x = X.col(j);
-    const double* __restrict__ xg = HALO ? xghost + j * ldghost : nullptr;
-    double sum = 0.0;
+  for (int j0 = 0; j0 < X.k; j0 += KT) {
+    // a tile of KT columns (KT > 1: contiguous column views only, see the launch site): the CH x KT gathers of a
+    // chunk are issued back to back; indices clamped into the row, entries past its end computed and discarded
+    const double* __restrict__ xc[KT];
+    const double* __restrict__ xgc[KT];
+#pragma unroll
+    for (int jj = 0; jj < KT; ++jj) {
+      const int j = min(j0 + jj, X.k - 1);
+      xc[jj] = X.col(j);
+      xgc[jj] = HALO ? xghost + j * ldghost : nullptr;
+    }
+    double sumt[KT];
+#pragma unroll
+    for (int jj = 0; jj < KT; ++jj) sumt[jj] = 0.0;
     for (int q0 = o0; q0 < o1; q0 += CH) {
-      // branch-free chunk (indices clamped into the row): CH column / value reads and CH gathers issued back to back
-      double v[CH], xv[CH];
+      double v[CH], xv[KT][CH];
       int cc[CH];
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
@@ -564,17 +573,26 @@ __global__ __launch_bounds__(CFG::SBLK) void k_spmv_rowgather(
         v[i] = sval[q];
       }
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        if (HALO) xv[i] = cc[i] >= nowned ? xg[cc[i] - nowned] : x[cc[i]];
-        else xv[i] = x[cc[i]];
-      }
+      for (int jj = 0; jj < KT; ++jj)
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const double s2 = sum + v[i] * xv[i];
-        sum = q0 + i < o1 ? s2 : sum;
-      }
+        for (int i = 0; i < CH; ++i) {
+          if (HALO) xv[jj][i] = cc[i] >= nowned ? xgc[jj][cc[i] - nowned] : xc[jj][cc[i]];
+          else xv[jj][i] = xc[jj][cc[i]];
+        }
+#pragma unroll
+      for (int jj = 0; jj < KT; ++jj)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const double s2 = sumt[jj] + v[i] * xv[jj][i];
+          sumt[jj] = q0 + i < o1 ? s2 : sumt[jj];
+        }
     }
-    if ((int)threadIdx.x < d.nr) __builtin_nontemporal_store(sum, Y.col(j) + d.r0 + threadIdx.x);
+    if ((int)threadIdx.x < d.nr)
+#pragma unroll
+      for (int jj = 0; jj < KT; ++jj)
+        if (j0 + jj < X.k) __builtin_nontemporal_store(sumt[jj], Y.col(j0 + jj) + d.r0 + threadIdx.x);
+    const int j = j0;
+    const double sum = sumt[0];
     if (DOT && j == 0) {
       double part = (int)threadIdx.x < d.nr ? sum * xdot[d.r0 + threadIdx.x] : 0.0;
 #pragma unroll
@@ -635,19 +653,27 @@ __device__ inline RgpBlk rgp_desc(const BlkDesc* __restrict__ desc, long long b)
   return d;
 }
 
-template <int AUX>
+// CPLX: an entry's value is 16 bytes (re, im): the 16 KiB value image holds 1024 entries, the block partition of a
+// complex matrix caps a block at RGP_NNZ_CAP_CPLX
+constexpr int RGP_NNZ_CAP_CPLX = 1020;
+template <int AUX, bool CPLX>
 __device__ inline void rgp_issue(const RgpBlk& d, const int* __restrict__ colidx, const double* __restrict__ vals,
                                  const unsigned short* __restrict__ roff16, long long b, double* sv, int* sc,
                                  unsigned short* sr) {
-  if (d.nnzb > RGP_NNZ_CAP) return;        // one over-long row: read in place by the whole workgroup
+  if (d.nnzb > (CPLX ? RGP_NNZ_CAP_CPLX : RGP_NNZ_CAP)) return;        // one over-long row: read in place
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long end = d.base + d.nnzb;
-  const long long lo = d.base & ~1LL, lo4 = d.base & ~3LL;
+  const long long lo = CPLX ? d.base : (d.base & ~1LL), lo4 = d.base & ~3LL;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {            // values: 16 pieces of 1 KiB, four per wave
     const int piece = wave + 4 * p;
-    const long long idx = lo + 128 * piece + 2 * lane;
-    if (idx < end) lds_dma16<AUX>(vals + idx, sv + 128 * piece);
+    if (CPLX) {
+      const long long idx = lo + 64 * piece + lane;                   // one complex entry per lane
+      if (idx < end) lds_dma16<AUX>(vals + 2 * idx, sv + 128 * piece);
+    } else {
+      const long long idx = lo + 128 * piece + 2 * lane;
+      if (idx < end) lds_dma16<AUX>(vals + idx, sv + 128 * piece);
+    }
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {            // columns: 8 pieces, two per wave
@@ -658,12 +684,16 @@ __device__ inline void rgp_issue(const RgpBlk& d, const int* __restrict__ colidx
   if (wave == 0 && 8 * lane <= d.nr) lds_dma16<0>(roff16 + b * RGP_ROFF_STRIDE + 8 * lane, sr);
 }
 
-// x, y: first column and leading dimension (contiguous column ranges; the host splits other views into ranges)
-template <int CH, int AUX>
+// x, y: first column and leading dimension in doubles (contiguous column ranges; the host splits other views into
+// ranges).  KT: columns whose gathers are in flight together (a block of k vectors is walked in tiles of KT columns
+// over the LDS-resident matrix entries).  CPLX: per entry (ar xr - ai xi, ar xi + ai xr), each product rounded, sums
+// in storage order - the arithmetic of oracle_spmv_complex.
+template <int CH, int AUX, bool CPLX = false, int KT = 1>
 __global__ __launch_bounds__(256) void k_spmv_rgp(
     const BlkDesc* __restrict__ desc, long long nblocks, const int* __restrict__ colidx,
     const double* __restrict__ vals, const unsigned short* __restrict__ roff16,
     const double* __restrict__ x0, long long ldx, double* __restrict__ y0, long long ldy, int k) {
+  constexpr int CAP = CPLX ? RGP_NNZ_CAP_CPLX : RGP_NNZ_CAP;
   __shared__ __attribute__((aligned(16))) double sval[2][2048];
   __shared__ __attribute__((aligned(16))) int scol[2][2048];
   __shared__ __attribute__((aligned(16))) unsigned short sroff[2][RGP_ROFF_STRIDE + 8];
@@ -675,7 +705,7 @@ __global__ __launch_bounds__(256) void k_spmv_rgp(
   if (b >= last) return;
   const int t = threadIdx.x;
   RgpBlk d = rgp_desc(desc, b), dn = d;
-  rgp_issue<AUX>(d, colidx, vals, roff16, b, sval[0], scol[0], sroff[0]);
+  rgp_issue<AUX, CPLX>(d, colidx, vals, roff16, b, sval[0], scol[0], sroff[0]);
   bool has_next = b + W < last;
   if (has_next) dn = rgp_desc(desc, b + W);
   for (int it = 0; b < last; b += W, ++it) {
@@ -685,51 +715,104 @@ __global__ __launch_bounds__(256) void k_spmv_rgp(
     RgpBlk dnn = dn;
     const bool has_nn = b + 2 * W < last;
     if (has_next) {
-      rgp_issue<AUX>(dn, colidx, vals, roff16, b + W, sval[s ^ 1], scol[s ^ 1], sroff[s ^ 1]);
+      rgp_issue<AUX, CPLX>(dn, colidx, vals, roff16, b + W, sval[s ^ 1], scol[s ^ 1], sroff[s ^ 1]);
       if (has_nn) dnn = rgp_desc(desc, b + 2 * W);
     }
-    if (d.nnzb > RGP_NNZ_CAP) {
+    if (d.nnzb > CAP) {
       for (int j = 0; j < k; ++j) {
         const double* x = x0 + j * ldx;
-        double sr = 0.0;
-        for (long long q = d.base + t; q < d.base + d.nnzb; q += 256) sr += vals[q] * x[colidx[q]];
+        double sr = 0.0, si = 0.0;
+        for (long long q = d.base + t; q < d.base + d.nnzb; q += 256) {
+          const int cc = colidx[q];
+          if (CPLX) {
+            const double ar = vals[2 * q], ai = vals[2 * q + 1], xr = x[2 * (long long)cc], xi = x[2 * (long long)cc + 1];
+            sr += ar * xr - ai * xi;
+            si += ar * xi + ai * xr;
+          } else {
+            sr += vals[q] * x[cc];
+          }
+        }
         __syncthreads();
         sval[s][t] = sr;
+        if (CPLX) sval[s][256 + t] = si;
         __syncthreads();
         if (t == 0) {
-          double tr = 0.0;
-          for (int q = 0; q < 256; ++q) tr += sval[s][q];
-          y0[j * ldy + d.r0] = tr;
+          double tr = 0.0, ti = 0.0;
+          for (int q = 0; q < 256; ++q) { tr += sval[s][q]; if (CPLX) ti += sval[s][256 + q]; }
+          if (CPLX) { y0[j * ldy + 2 * (long long)d.r0] = tr; y0[j * ldy + 2 * (long long)d.r0 + 1] = ti; }
+          else y0[j * ldy + d.r0] = tr;
         }
       }
     } else {
-      const double* __restrict__ sv = sval[s] + (int)(d.base & 1);
       const int* __restrict__ sc = scol[s] + (int)(d.base & 3);
       int o0 = 0, o1 = 0;
       if (t < d.nr) { o0 = sroff[s][t]; o1 = sroff[s][t + 1]; }
-      for (int j = 0; j < k; ++j) {
-        const double* __restrict__ x = x0 + j * ldx;
-        double sum = 0.0;
-        for (int q0 = o0; q0 < o1; q0 += CH) {
-          // branch-free chunk: indices clamped into the row, so the CH column / value reads and the CH gathers are
-          // issued back to back; entries past the row's end are computed and discarded
-          double v[CH], xv[CH];
-          int cc[CH];
+      if (CPLX) {
+        const dbl2* __restrict__ sv = reinterpret_cast<const dbl2*>(sval[s]);
+        for (int j = 0; j < k; ++j) {
+          const dbl2* __restrict__ x = reinterpret_cast<const dbl2*>(x0 + j * ldx);
+          double sr = 0.0, si = 0.0;
+          for (int q0 = o0; q0 < o1; q0 += CH) {
+            dbl2 v[CH], xv[CH];
+            int cc[CH];
 #pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            const int q = min(q0 + i, o1 - 1);
-            cc[i] = sc[q];
-            v[i] = sv[q];
+            for (int i = 0; i < CH; ++i) {
+              const int q = min(q0 + i, o1 - 1);
+              cc[i] = sc[q];
+              v[i] = sv[q];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) xv[i] = x[cc[i]];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+              const double pr = v[i].x * xv[i].x - v[i].y * xv[i].y;
+              const double pi = v[i].x * xv[i].y + v[i].y * xv[i].x;
+              const double r2 = sr + pr, i2 = si + pi;
+              sr = q0 + i < o1 ? r2 : sr;
+              si = q0 + i < o1 ? i2 : si;
+            }
           }
-#pragma unroll
-          for (int i = 0; i < CH; ++i) xv[i] = x[cc[i]];
-#pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            const double s2 = sum + v[i] * xv[i];
-            sum = q0 + i < o1 ? s2 : sum;
+          if (t < d.nr) {
+            dbl2 out2; out2.x = sr; out2.y = si;
+            __builtin_nontemporal_store(out2, reinterpret_cast<dbl2*>(y0 + j * ldy) + d.r0 + t);
           }
         }
-        if (t < d.nr) __builtin_nontemporal_store(sum, y0 + j * ldy + d.r0 + t);
+      } else {
+        const double* __restrict__ sv = sval[s] + (int)(d.base & 1);
+        for (int j0 = 0; j0 < k; j0 += KT) {
+          // a tile of KT columns: the CH x KT gathers of a chunk are issued back to back (indices clamped into the
+          // row; entries past the row's end are computed and discarded)
+          double sum[KT];
+#pragma unroll
+          for (int jj = 0; jj < KT; ++jj) sum[jj] = 0.0;
+          for (int q0 = o0; q0 < o1; q0 += CH) {
+            double v[CH], xv[KT][CH];
+            int cc[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+              const int q = min(q0 + i, o1 - 1);
+              cc[i] = sc[q];
+              v[i] = sv[q];
+            }
+#pragma unroll
+            for (int jj = 0; jj < KT; ++jj) {
+              const double* __restrict__ x = x0 + min(j0 + jj, k - 1) * ldx;
+#pragma unroll
+              for (int i = 0; i < CH; ++i) xv[jj][i] = x[cc[i]];
+            }
+#pragma unroll
+            for (int jj = 0; jj < KT; ++jj)
+#pragma unroll
+              for (int i = 0; i < CH; ++i) {
+                const double s2 = sum[jj] + v[i] * xv[jj][i];
+                sum[jj] = q0 + i < o1 ? s2 : sum[jj];
+              }
+          }
+          if (t < d.nr)
+#pragma unroll
+            for (int jj = 0; jj < KT; ++jj)
+              if (j0 + jj < k) __builtin_nontemporal_store(sum[jj], y0 + (j0 + jj) * ldy + d.r0 + t);
+        }
       }
     }
     d = dn; dn = dnn; has_next = has_nn;
@@ -1361,7 +1444,11 @@ void launch_stream(mxg_ctx* c, const mxg_csr* a, const MvDesc& X, const MvDesc& 
 template <typename CFG>
 static int build_xwin(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx);
 static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr);
-constexpr int MXG_KERNEL_DEFAULT = 0x2750000;  // persistent LDS-DMA row-gather (2048-nnz blocks, gather chunk 7, 16-bit in-block row offsets)
+// row-gather, one 2048-nnz block per workgroup, gather chunk 7, 16-bit in-block row offsets.  The persistent LDS-DMA
+// variant (| 0x2000000, k_spmv_rgp) measures the same at k = 1 (0.400 vs 0.394 ms on one box, 0.3585 vs 0.3761 before the
+// branch-free row walk reached this kernel too) and loses at k >= 4 (12 instead of 24 waves per CU); complex matrices
+// use it (their one-block kernel is the older stream kernel).
+constexpr int MXG_KERNEL_DEFAULT = 0x750000;
 
 extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, int64_t nghost,
                               const int64_t* rowptr, const int32_t* colidx, const double* vals,
@@ -1438,6 +1525,10 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
     // 7-point bulk rows of the vector Laplacian; 70.8 % of HBM peak at 256^3)
     MXG_TRY(build_pipe_desc(a, 10, rowptr));
     a->kernel = MXG_KERNEL_DEFAULT;
+  } else if (a->is_complex && nnz > 0) {
+    // complex scalars (Bloch phases, lossy dielectrics): the same persistent row-gather kernel over 16-byte values
+    MXG_TRY(build_pipe_desc(a, 12, rowptr));
+    a->kernel = MXG_KERNEL_DEFAULT | 0x2000000;
   } else if (!a->is_complex) {
     // a rank of a decomposed grid that owns nothing: same kernel family as everybody else (zero row blocks), so that
     // every rank takes the same solver path and issues the same sequence of collectives
@@ -1612,6 +1703,7 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
   int rows_cap = 2 * (geo == 0 ? PipeCfgA::SBLK : PipeCfgB::SBLK);
   if (geo == 10) { cap = RGP_NNZ_CAP; rows_cap = RgCfgA::ROWS_CAP; }   // 2044: the persistent kernel's 16-byte aligned LDS image
   if (geo == 11) { cap = RgCfgB::NNZ_CAP; rows_cap = RgCfgB::ROWS_CAP; }
+  if (geo == 12) { cap = RGP_NNZ_CAP_CPLX; rows_cap = RgCfgA::ROWS_CAP; }   // complex matrix, persistent row-gather kernel
   std::vector<int32_t> blk = build_row_blocks(host_rowptr, a->nrows, cap, rows_cap);
   std::vector<BlkDesc> desc(blk.size() - 1);
   for (size_t b = 0; b + 1 < blk.size(); ++b) {
@@ -1660,7 +1752,7 @@ static int build_pipe_desc(mxg_csr* a, int geo, const int64_t* host_rowptr) {
     MXG_HIP(hipMemcpyAsync(a->d_blkdesc, desc.data(), sizeof(BlkDesc) * desc.size(),
                            hipMemcpyHostToDevice, c->stream));
   if (a->d_roff16) { hipFree(a->d_roff16); a->d_roff16 = nullptr; }
-  if (geo == 10) {
+  if (geo == 10 || geo == 12) {
     // persistent kernel: the same offsets, RGP_ROFF_STRIDE ushorts per block in descriptor order, so that a block's
     // offsets are one 16-byte aligned LDS-DMA piece
     std::vector<unsigned short> r16(desc.size() * (size_t)RGP_ROFF_STRIDE + 8, 0);
@@ -2238,8 +2330,8 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
     // persistent double-buffered row-gather kernel: 3 workgroups (2 x 24.5 KiB of LDS each) per CU
     const unsigned grid = (unsigned)std::max(MXG_NUM_XCD, (c->num_cu * 3 / MXG_NUM_XCD) * MXG_NUM_XCD);
     const int ch = (a->kernel >> 20) & 0xF;
-#define MXG_RGP(CHV, AUX)                                                                            \
-    hipLaunchKernelGGL((k_spmv_rgp<CHV, AUX>), dim3(grid), dim3(256), 0, c->stream, (const BlkDesc*)a->d_blkdesc, \
+#define MXG_RGP(CHV, AUX, KTV)                                                                       \
+    hipLaunchKernelGGL((k_spmv_rgp<CHV, AUX, false, KTV>), dim3(grid), dim3(256), 0, c->stream, (const BlkDesc*)a->d_blkdesc, \
                        (long long)a->npipe, (const int*)a->d_colidx, (const double*)a->d_vals,          \
                        (const unsigned short*)a->d_roff16, (const double*)X.base + X.ld * xc0, (long long)X.ld, \
                        Y.base + Y.ld * yc0, (long long)Y.ld, kk)
@@ -2248,8 +2340,10 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
       int kk = 1;
       while (j0 + kk < X.k && x->hcols[j0 + kk] == x->hcols[j0] + kk && y->hcols[j0 + kk] == y->hcols[j0] + kk) ++kk;
       const long long xc0 = X.base == x->base ? x->hcols[j0] : j0, yc0 = y->hcols[j0];
-      if (a->kernel & 0x4000000) { if (ch == 4) MXG_RGP(4, 0); else if (ch == 7) MXG_RGP(7, 0); else MXG_RGP(8, 0); }
-      else { if (ch == 4) MXG_RGP(4, 2); else if (ch == 7) MXG_RGP(7, 2); else MXG_RGP(8, 2); }
+      if (a->kernel & 0x4000000) { if (ch == 4) MXG_RGP(4, 0, 1); else if (ch == 7) MXG_RGP(7, 0, 1); else MXG_RGP(8, 0, 1); }
+      else if (kk >= 4 && ch == 7) MXG_RGP(7, 2, 4);
+      else if (kk >= 2 && ch == 7) MXG_RGP(7, 2, 2);
+      else { if (ch == 4) MXG_RGP(4, 2, 1); else if (ch == 7) MXG_RGP(7, 2, 1); else MXG_RGP(8, 2, 1); }
       j0 += kk;
     }
 #undef MXG_RGP
@@ -2257,14 +2351,21 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
     const long long per = (a->npipe + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
     const int ch = (a->kernel >> 20) & 0xF;   // gather chunk: 0 -> 8
-#define MXG_RG(CFG, CHV)                                                                           \
-    hipLaunchKernelGGL((k_spmv_rowgather<CFG, CHV>), dim3(grid), dim3(CFG::SBLK), 0, c->stream,       \
+#define MXG_RG(CFG, CHV) MXG_RGK(CFG, CHV, 1)
+#define MXG_RGK(CFG, CHV, KTV)                                                                     \
+    hipLaunchKernelGGL((k_spmv_rowgather<CFG, CHV, false, false, KTV>), dim3(grid), dim3(CFG::SBLK), 0, c->stream, \
                        (const BlkDesc*)a->d_blkdesc, (long long)a->npipe, (const long long*)a->d_rowptr, \
                        a->d_colidx, a->d_vals, X, Y, (const double*)nullptr, (double*)nullptr,       \
                        (a->kernel & 0x40000) ? (const unsigned short*)a->d_roff : (const unsigned short*)nullptr)
-    if (a->pipe_geo == 10) { if (ch == 4) MXG_RG(RgCfgA, 4); else if (ch == 7) MXG_RG(RgCfgA, 7); else MXG_RG(RgCfgA, 8); }
+    // (column tiles - KT = 2 / 4 gathers of a chunk in flight per column tile - measured slower here: 0.566 / 0.780 /
+    //  1.344 ms against 0.516 / 0.748 / 1.206 ms at k = 2 / 4 / 8, the registers cost a block per CU; MXG_SPMM_TILE=1)
+    static const bool tile = getenv("MXG_SPMM_TILE") != nullptr;
+    if (tile && a->pipe_geo == 10 && ch == 7 && X.k >= 4) MXG_RGK(RgCfgA, 7, 4);
+    else if (tile && a->pipe_geo == 10 && ch == 7 && X.k >= 2) MXG_RGK(RgCfgA, 7, 2);
+    else if (a->pipe_geo == 10) { if (ch == 4) MXG_RG(RgCfgA, 4); else if (ch == 7) MXG_RG(RgCfgA, 7); else MXG_RG(RgCfgA, 8); }
     else { if (ch == 4) MXG_RG(RgCfgB, 4); else if (ch == 7) MXG_RG(RgCfgB, 7); else MXG_RG(RgCfgB, 8); }
 #undef MXG_RG
+#undef MXG_RGK
   } else if ((a->kernel & 0xC000) && !a->is_complex && a->nxw > 0) {
     const long long per = (a->nxw + MXG_NUM_XCD - 1) / MXG_NUM_XCD;
     const unsigned grid = (unsigned)(per * MXG_NUM_XCD);
@@ -2297,6 +2398,18 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
     hipLaunchKernelGGL((k_spmv_vector<8>), dim3((unsigned)((threads + SBLK - 1) / SBLK)), dim3(SBLK),
                        0, c->stream, (const long long*)a->d_rowptr, a->d_colidx, a->d_vals,
                        (long long)a->nrows, X, Y);
+  } else if (a->is_complex && (a->kernel & 0x2000000) && a->pipe_geo == 12 && a->npipe > 0 && a->d_roff16 && !halo) {
+    const unsigned grid = (unsigned)std::max(MXG_NUM_XCD, (c->num_cu * 3 / MXG_NUM_XCD) * MXG_NUM_XCD);
+    for (int j0 = 0; j0 < X.k;) {
+      int kk = 1;
+      while (j0 + kk < X.k && x->hcols[j0 + kk] == x->hcols[j0] + kk && y->hcols[j0 + kk] == y->hcols[j0] + kk) ++kk;
+      const long long xc0 = X.base == x->base ? x->hcols[j0] : j0, yc0 = y->hcols[j0];
+      hipLaunchKernelGGL((k_spmv_rgp<7, 2, true, 1>), dim3(grid), dim3(256), 0, c->stream, (const BlkDesc*)a->d_blkdesc,
+                         (long long)a->npipe, (const int*)a->d_colidx, (const double*)a->d_vals,
+                         (const unsigned short*)a->d_roff16, (const double*)X.base + X.ld * xc0, (long long)X.ld,
+                         Y.base + Y.ld * yc0, (long long)Y.ld, kk);
+      j0 += kk;
+    }
   } else if (a->is_complex) {
     launch_stream<true, CfgDefault, true, true>(c, a, X, Y);
   } else if (a->kernel & 0x3000) {

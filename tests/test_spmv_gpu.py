@@ -104,16 +104,34 @@ def test_views_of_noncontiguous_columns(ctx, oracle_pillbox12, rng):
     assert np.array_equal(got[:, [1, 3, 0]], want) and np.all(got[:, [2, 4]] == 0)
 
 
-def test_complex_matrix(ctx, rng):
+@pytest.mark.parametrize("code", [None, 0x0])
+def test_complex_matrix(ctx, rng, code):
     """Complex scalars are interleaved pairs (the reference's 2x2 real embedding,
-    src/MxCrsMatrix.cpp:146-170, collapses to complex multiply-add)."""
+    src/MxCrsMatrix.cpp:146-170, collapses to complex multiply-add).  Default: the persistent row-gather kernel
+    over 16-byte values; code 0: the one-block-per-workgroup stream kernel.  Includes an over-long row, empty rows
+    and views of scattered columns."""
     n = 3000
-    m = sp.random(n, n, density=4.0 / n, random_state=7, format="csr") \
-        + 1j * sp.random(n, n, density=4.0 / n, random_state=8, format="csr")
-    m = m.tocsr(); m.sort_indices()
-    x = rng.uniform(-1, 1, (n, 2)) + 1j * rng.uniform(-1, 1, (n, 2))
-    got = _apply(ctx, m, x)
-    assert np.array_equal(got, cref.spmv(m, x))
+    m = (sp.random(n, n, density=4.0 / n, random_state=7, format="csr")
+         + 1j * sp.random(n, n, density=4.0 / n, random_state=8, format="csr")).tolil()
+    m[5, :1500] = rng.uniform(-1, 1, 1500) + 1j * rng.uniform(-1, 1, 1500)      # longer than a block
+    for r in range(700, 1100):
+        m[r, :] = 0
+    m = m.tocsr(); m.eliminate_zeros(); m.sort_indices()
+    x = rng.uniform(-1, 1, (n, 3)) + 1j * rng.uniform(-1, 1, (n, 3))
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    if code is not None:
+        A.set_kernel(code)
+    X = mx.MultiVec.from_numpy(ctx, x)
+    Y = mx.MultiVec(ctx, n, 3, True)
+    A.apply(X, Y)
+    got, want = Y.to_numpy(), cref.spmv(m, x)
+    mask = np.ones(n, bool); mask[5] = False
+    assert np.array_equal(got[mask], want[mask])
+    assert np.abs(got[5] - want[5]).max() <= 1e-12 * np.abs(m[5].data).sum()
+    Y.fill(0.0)
+    A.apply(X.view([2, 0]), Y.view([0, 2]))
+    got = Y.to_numpy()
+    assert np.array_equal(got[mask][:, [0, 2]], want[mask][:, [2, 0]]) and np.all(got[:, 1] == 0)
 
 
 def test_ragged_rows_empty_rows_and_long_row(ctx, rng):
