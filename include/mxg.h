@@ -97,6 +97,17 @@ int mxg_csr_create(mxg_ctx* ctx, int64_t nrows, int64_t ncols_owned, int64_t ngh
                    const int64_t* rowptr, const int32_t* colidx, const double* vals,
                    int is_complex, const mxg_halo_plan* plan, mxg_csr** out);
 int mxg_csr_destroy(mxg_csr* a);
+/* Setup-time sparse algebra on the device (real matrices without ghosts), bit-identical to the host versions:
+ *   multiply: C = A B        MxCrsMatrix::matrixMatrixMultiply (src/MxCrsMatrix.cpp:361-382; the chain of
+ *                            MxUtil::Trilinos::massiveCrsMultiply, src/MxUtil.cpp:318-371)
+ *   add:      C = sa A + sb B MxCrsMatrix::matrixMatrixAdd (src/MxCrsMatrix.cpp:404-457; setShift, src/MxMagWaveOp.cpp:248-255)
+ *   purge:    keep |a| > tol MxCrsMatrix::purgeZeros (src/MxCrsMatrix.cpp:84-116)
+ * The result is a new matrix owned by the caller (mxg_csr_destroy).  download copies the CSR arrays to the host
+ * (NULL = not wanted): MxCrsMatrix::getLocalRow / save and the multigrid setup read them. */
+int mxg_csr_multiply(mxg_ctx* ctx, const mxg_csr* a, const mxg_csr* b, mxg_csr** out);
+int mxg_csr_add(mxg_ctx* ctx, const mxg_csr* a, double sa, const mxg_csr* b, double sb, mxg_csr** out);
+int mxg_csr_purge(mxg_ctx* ctx, const mxg_csr* a, double tol, mxg_csr** out);
+int mxg_csr_download(const mxg_csr* a, int64_t* rowptr, int32_t* colidx, double* vals);
 int mxg_csr_info(const mxg_csr* a, int64_t* nrows, int64_t* ncols_owned, int64_t* nghost,
                  int64_t* nnz, int* is_complex);
 /* y = A x  (SpMV for 1 column, SpMM for k columns).  MxCrsMatrix<S>::apply,

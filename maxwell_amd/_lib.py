@@ -61,6 +61,10 @@ MXG_SIGNATURES = {
     "mxg_csr_create": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, C.c_int,
                                  C.POINTER(HaloPlan), C.POINTER(vp)]),
     "mxg_csr_destroy": (C.c_int, [vp]),
+    "mxg_csr_multiply": (C.c_int, [vp, vp, vp, C.POINTER(vp)]),
+    "mxg_csr_add": (C.c_int, [vp, vp, C.c_double, vp, C.c_double, C.POINTER(vp)]),
+    "mxg_csr_purge": (C.c_int, [vp, vp, C.c_double, C.POINTER(vp)]),
+    "mxg_csr_download": (C.c_int, [vp, vp, vp, vp]),
     "mxg_csr_info": (C.c_int, [vp, c_i64p, c_i64p, c_i64p, c_i64p, c_ip]),
     "mxg_csr_apply": (C.c_int, [vp, vp, vp, vp]),
     "mxg_csr_apply_bytes": (C.c_int64, [vp, C.c_int]),

