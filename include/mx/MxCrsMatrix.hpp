@@ -93,17 +93,19 @@ class MxCrsMatrix {
     adopt(m);
   }
 
-  void scale(Scalar val) { mx::scaleInPlace(mHost, val); upload(); }
+  void scale(Scalar val) { host(); mx::scaleInPlace(mHost, val); upload(); }
   void leftScale(RCP<MxVector<Scalar> > vec) {
     std::vector<Scalar> d;
     vec->getColumn(0, d);
     mx::UVec<Scalar> dd(d.begin(), d.end());
+    host();
     for (int64_t i = 0; i < mHost.nrows; ++i)
       for (int64_t p = mHost.rowptr[i]; p < mHost.rowptr[i + 1]; ++p) mHost.val[p] *= dd[i];
     upload();
   }
   void getLocalRow(MxIndex localRowIndex, std::vector<MxIndex>& localColIndices, std::vector<Scalar>& vals) const {
     localColIndices.clear(); vals.clear();
+    host();
     for (int64_t p = mHost.rowptr[localRowIndex]; p < mHost.rowptr[localRowIndex + 1]; ++p) {
       localColIndices.push_back((MxIndex)mHost.col[p]);
       vals.push_back(mHost.val[p]);
@@ -111,6 +113,7 @@ class MxCrsMatrix {
   }
   RCP<MxVector<Scalar> > getRowSums(bool inverse) const {
     RCP<MxVector<Scalar> > res = rcp(new MxVector<Scalar>(mRowMap));
+    host();
     std::vector<Scalar> s(mHost.nrows);
     for (int64_t i = 0; i < mHost.nrows; ++i) {
       Scalar sum = Scalar(0);   // the reference never resets `sum` (src/MxCrsMatrix.cpp:306-311)
@@ -132,6 +135,7 @@ class MxCrsMatrix {
   void save(std::string name) const {
     std::ofstream f((name + ".mm").c_str());
     f.precision(17);
+    host();
     f << "%%MatrixMarket matrix coordinate " << (ScalarTraits<Scalar>::isComplex ? "complex" : "real") << " general\n";
     f << mRowMap->getGlobalNumIndices() << " " << mColMap->getGlobalNumIndices() << " " << mHost.nnz() << "\n";
     for (int64_t i = 0; i < mHost.nrows; ++i)
@@ -142,7 +146,18 @@ class MxCrsMatrix {
       }
   }
 
-  void purgeZeros() { mx::Csr<Scalar> p = mx::purge(mHost); adopt(p); }   // |a| > 1e-12 kept
+  void purgeZeros() {   // |a| > 1e-12 kept
+    if (mDev && !mHostValid) {          // born on the device: purge there (mxg_csr_purge, same rule)
+      mxg_csr* r = nullptr;
+      MX_ABI(mxg_csr_purge(mRowMap->getComm()->getCtx(), mDev, 1.e-12, &r), "MxCrsMatrix::purgeZeros");
+      mxg_csr_destroy(mDev);
+      mDev = r;
+      mCompressed = false;
+      return;
+    }
+    mx::Csr<Scalar> p = mx::purge(mHost);
+    adopt(p);
+  }
 
   void fillComplete() { fillComplete(mColMap, mRowMap); }
   bool isFilled() const { return mFilled; }
@@ -151,42 +166,100 @@ class MxCrsMatrix {
 
   static void matrixMatrixMultiply(MxCrsMatrix<Scalar> const& a, bool transA, MxCrsMatrix<Scalar> const& b,
                                    bool transB, MxCrsMatrix<Scalar>& result, bool fc) {
-    mx::Csr<Scalar> ta, tb;
-    const mx::Csr<Scalar>& A = transA ? (ta = mx::transpose(a.mHost, true)) : a.mHost;
-    const mx::Csr<Scalar>& B = transB ? (tb = mx::transpose(b.mHost, true)) : b.mHost;
     result.mRowMap = transA ? a.mColMap : a.mRowMap;
     result.mColMap = transB ? b.mRowMap : b.mColMap;
-    mx::Csr<Scalar> c = mx::multiply(A, B);
     (void)fc;
+    if (!transA && !transB && deviceAlgebra(a, b)) {
+      // the product is formed on the GPU (mxg_csr_multiply: the arithmetic and order of mx::multiply, bit for bit);
+      // a host copy is only made if somebody asks for one (getHostCsr, getLocalRow, save)
+      a.ensureDevice(false); b.ensureDevice(false);
+      mxg_csr* r = nullptr;
+      MX_ABI(mxg_csr_multiply(a.mRowMap->getComm()->getCtx(), a.mDev, b.mDev, &r), "MxCrsMatrix::matrixMatrixMultiply");
+      result.adoptDevice(r);
+      return;
+    }
+    mx::Csr<Scalar> ta, tb;
+    const mx::Csr<Scalar>& A = transA ? (ta = mx::transpose(a.host(), true)) : a.host();
+    const mx::Csr<Scalar>& B = transB ? (tb = mx::transpose(b.host(), true)) : b.host();
+    mx::Csr<Scalar> c = mx::multiply(A, B);
     result.adopt(c);
   }
   static void matrixMatrixAdd(MxCrsMatrix<Scalar> const& a, bool transA, Scalar scalarA,
                               MxCrsMatrix<Scalar> const& b, bool transB, Scalar scalarB,
                               MxCrsMatrix<Scalar>& result, bool fc) {
-    mx::Csr<Scalar> ta, tb;
-    const mx::Csr<Scalar>& A = transA ? (ta = mx::transpose(a.mHost, true)) : a.mHost;
-    const mx::Csr<Scalar>& B = transB ? (tb = mx::transpose(b.mHost, true)) : b.mHost;
     result.mRowMap = transA ? a.mColMap : a.mRowMap;
     result.mColMap = transA ? a.mRowMap : a.mColMap;
-    mx::Csr<Scalar> c = mx::add(A, scalarA, B, scalarB);
     (void)fc;
+    if (!transA && !transB && deviceAlgebra(a, b)) {
+      a.ensureDevice(false); b.ensureDevice(false);
+      mxg_csr* r = nullptr;
+      MX_ABI(mxg_csr_add(a.mRowMap->getComm()->getCtx(), a.mDev, mxRe(scalarA), b.mDev, mxRe(scalarB), &r), "MxCrsMatrix::matrixMatrixAdd");
+      result.adoptDevice(r);
+      return;
+    }
+    mx::Csr<Scalar> ta, tb;
+    const mx::Csr<Scalar>& A = transA ? (ta = mx::transpose(a.host(), true)) : a.host();
+    const mx::Csr<Scalar>& B = transB ? (tb = mx::transpose(b.host(), true)) : b.host();
+    mx::Csr<Scalar> c = mx::add(A, scalarA, B, scalarB);
     result.adopt(c);
   }
 
   // host-side CSR (setup algebra, tests) and device handle (advanced usage)
-  mx::Csr<Scalar> const& getHostCsr() const { return mHost; }
+  mx::Csr<Scalar> const& getHostCsr() const { return host(); }
   mxg_csr* getRawMatrix() const { ensureDevice(); return mDev; }
+  // the setup-time products / sums of real, single-rank matrices run on the GPU (MXH_DEVICE_CHAIN=0: on the host)
+  static bool deviceChainEnabled() {
+    static const bool on = !(getenv("MXH_DEVICE_CHAIN") && atoi(getenv("MXH_DEVICE_CHAIN")) == 0);
+    return on;
+  }
 
  private:
   void initRows() { mRows.resize(mRowMap->getNodeNumIndices()); }
   // the device copy is created on first use: setup-only intermediates never reach the GPU
-  void adopt(mx::Csr<Scalar> const& m) { mHost = m; upload(); }
+  void adopt(mx::Csr<Scalar> const& m) { mHost = m; mHostValid = true; upload(); }
   void upload() {
     if (mDev) { mxg_csr_destroy(mDev); mDev = nullptr; }
+    mCompressed = false;
     mFilled = true;
   }
-  void ensureDevice() const {
-    if (mDev) return;
+  // a matrix formed on the device: the handle is the matrix, the host copy follows on demand
+  void adoptDevice(mxg_csr* r) {
+    if (mDev) mxg_csr_destroy(mDev);
+    mDev = r;
+    mHost = mx::Csr<Scalar>();
+    mHostValid = false;
+    mCompressed = false;
+    mFilled = true;
+    mRows.clear();
+  }
+  static bool deviceAlgebra(MxCrsMatrix<Scalar> const& a, MxCrsMatrix<Scalar> const& b) {
+    return deviceChainEnabled() && !ScalarTraits<Scalar>::isComplex && !a.mDistributed && !b.mDistributed &&
+           a.mRowMap->getComm()->numProc() == 1;
+  }
+  mx::Csr<Scalar> const& host() const {
+    if (!mHostValid) {
+      int64_t nr = 0, nc = 0, ng = 0, nz = 0;
+      int cx = 0;
+      MX_ABI(mxg_csr_info(mDev, &nr, &nc, &ng, &nz, &cx), "MxCrsMatrix (host copy)");
+      mHost.nrows = nr; mHost.ncols = nc + ng;
+      mHost.rowptr.resize(nr + 1);
+      mHost.col.resize(nz);
+      mHost.val.resize(nz);
+      MX_ABI(mxg_csr_download(mDev, mHost.rowptr.data(), mHost.col.data(), reinterpret_cast<double*>(mHost.val.data())),
+             "MxCrsMatrix (host copy)");
+      mHostValid = true;
+    }
+    return mHost;
+  }
+  void ensureDevice(bool compressIt = true) const {
+    static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
+    if (mDev) {
+      if (compressIt && compress && !mCompressed && !ScalarTraits<Scalar>::isComplex && mRowMap->getNodeNumIndices() >= 256) {
+        MX_ABI(mxg_csr_compress(mDev, NULL, NULL, NULL), "MxCrsMatrix (compress)");
+        mCompressed = true;
+      }
+      return;
+    }
     mxg_halo_plan plan;
     plan.nneigh = (int)mNeigh.size();
     plan.neigh = mNeigh.data();
@@ -200,11 +273,12 @@ class MxCrsMatrix {
     // structured operators stream 3 bytes per entry instead of 12 (mxg_csr_compress; bit-identical results);
     // MXG_COMPRESS=0 keeps the plain CSR kernels.  With ghost columns the blocks that reference none are ordered
     // first and overlap the halo exchange, exactly as with the CSR kernel.
-    static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
-    if (compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 256)
+    if (compressIt && compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 256) {
       MX_ABI(mxg_csr_compress_from(mDev, mHost.rowptr.data(), mHost.col.data(),
                                    reinterpret_cast<const double*>(mHost.val.data()), NULL, NULL, NULL),
              "MxCrsMatrix::fillComplete (compress)");
+      mCompressed = true;
+    }
   }
   // ghosts = the global column ids this rank does not own, grouped by owner (ascending rank, then ascending id);
   // local column numbering [owned | ghosts].  One all-gather of the need lists gives every rank its send side.
@@ -359,7 +433,9 @@ class MxCrsMatrix {
   bool mFilled;
   RCP<MxMap> mRowMap, mColMap;
   std::vector<std::vector<std::pair<MxIndex, Scalar> > > mRows;
-  mx::Csr<Scalar> mHost;
+  mutable mx::Csr<Scalar> mHost;     // (filled on demand for a matrix formed on the device: host())
+  mutable bool mHostValid = true;
+  mutable bool mCompressed = false;
   mutable mxg_csr* mDev;
 };
 

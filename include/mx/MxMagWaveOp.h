@@ -195,7 +195,18 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
                    "(MxEMSim::setPrebuiltOps)\n";
       throw 1;
     }
-    mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim));
+    {
+      // single operators the sim has already assembled (device-chain mode of mxh_sim) are adopted instead of being
+      // assembled a second time; the products below then run through MxCrsMatrix::matrixMatrixMultiply / Add - on
+      // the GPU when MXH_DEVICE_CHAIN is set
+      auto pre = mSim->prebuiltOps((Scalar*)0);
+      if (pre && pre->count("curlE") && pre->count("curlB") && pre->count("divB") && pre->count("gradPsi")) {
+        mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim, false));
+        mEMOps->setSource(pre);
+      } else {
+        mEMOps = rcp(new MxEMOps<DIM, Scalar>(mSim));
+      }
+    }
     std::vector<std::string> names;
     names.push_back("curlB");
     if (mSim->hasDielectric()) names.push_back("invEps");

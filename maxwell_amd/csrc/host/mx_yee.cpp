@@ -843,24 +843,30 @@ Csr<S> YeeAssembler<S>::multiplyOps(const std::map<std::string, Csr<S>>& ops,
 }
 
 template <typename S>
-std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps() const {   // src/MxMagWaveOp.cpp:138-245
+std::map<std::string, Csr<S>> YeeAssembler<S>::singleOps() const {   // MxEMOps::setSingleOps, src/MxEMOps.cpp:39-168
   std::map<std::string, Csr<S>> o;
-  Tick tick;
   o["curlE"] = curlE();
   o["curlB"] = curlB();
   o["divB"] = divB();
   o["gradPsi"] = gradPsi();
-  const bool pec = hasPec();
-  if (pec) {
+  if (hasPec()) {
     o["dmA"] = fracs(B_, false);
     o["dmL"] = fracs(E_, false);
     o["dmVInv"] = fracs(P_, true);
   }
-  const bool diel = hasDielectric();
-  if (diel) {                                                              // src/MxEMOps.cpp:66-77
+  if (hasDielectric()) {                                                   // src/MxEMOps.cpp:66-77
     o["invEps"] = invEps();
     o["invEpsVolAve"] = invEpsVolAve();
   }
+  return o;
+}
+
+template <typename S>
+std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps() const {   // src/MxMagWaveOp.cpp:138-245
+  Tick tick;
+  std::map<std::string, Csr<S>> o = singleOps();
+  const bool pec = hasPec();
+  const bool diel = hasDielectric();
   tick("primitives");
   auto opt = [&](std::vector<std::string>& v, const char* nm) { if (pec) v.push_back(nm); };
   std::vector<std::string> names;

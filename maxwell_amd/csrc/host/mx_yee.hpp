@@ -108,6 +108,8 @@ class YeeAssembler {
 
   // name -> matrix: curlE curlB divB gradPsi [dmA dmL dmVInv] curlCurl gradDiv vecLapl scaLapl mRhs
   std::map<std::string, Csr<S>> waveOps() const;
+  // the single Yee operators only (the products are then formed elsewhere: on the device, MXH_DEVICE_CHAIN)
+  std::map<std::string, Csr<S>> singleOps() const;
   // massiveCrsMultiply order: first name applied first, m_k * (... * (m_1 * m_0))
   static Csr<S> multiplyOps(const std::map<std::string, Csr<S>>& ops,
                             const std::vector<std::string>& names);

@@ -17,6 +17,7 @@ struct mxh_sim {
   std::map<double, mx::Csr<double>> shifted;
   std::vector<double> mask;
   double setup_seconds = 0.0;
+  bool chain_ready = true;   // false: only the single operators are in `ops` yet (MXH_DEVICE_CHAIN), see mxh_sim_ensure_chain
   // distributed exports (kept alive for the borrowed pointers)
   struct DistOp {
     mx::UVec<int64_t> rowptr, colgid, rowgid, colowned;
@@ -28,5 +29,6 @@ struct mxh_sim {
 void mxh_set_error(const std::string& s);
 std::shared_ptr<const mx::Shape> mxh_parse_shape(const char* spec);
 const mx::Csr<double>& mxh_sim_shifted_matrix(mxh_sim* s, double shift);
+void mxh_sim_ensure_chain(mxh_sim* s);
 
 #endif

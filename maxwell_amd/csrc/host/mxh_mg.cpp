@@ -61,7 +61,7 @@ extern "C" int mxh_mg_create(mxg_ctx* ctx, mxh_sim* sim, const char* op, double 
     const mx::Csr<double>* A0;
     const mx::YeeField* F;
     if (nm == "shifted") { A0 = &mxh_sim_shifted_matrix(sim, shift); F = &sim->asmb->bfield(); }
-    else if (nm == "scaLapl") { A0 = &sim->ops.at("scaLapl"); F = &sim->asmb->psifield(); }
+    else if (nm == "scaLapl") { mxh_sim_ensure_chain(sim); A0 = &sim->ops.at("scaLapl"); F = &sim->asmb->psifield(); }
     else throw std::runtime_error("mxh_mg_create: operator must be 'shifted' or 'scaLapl'");
     *out = mxh_mg_build(ctx, *A0, *F, sim->cfg.n, min_coarse, max_levels, sweeps, coarse_sweeps, omega, coarse_scale);
     return 0;

@@ -148,7 +148,12 @@ extern "C" int mxh_sim_create_ex(const int n[3], const double origin[3], const d
     mxh_sim* s = new mxh_sim();
     s->cfg = cfg;
     s->asmb.reset(new mx::YeeAssembler<double>(cfg));
-    s->ops = s->asmb->waveOps();
+    // Single rank: only the single operators are assembled here; MxMagWaveOp forms the chain of products on the GPU
+    // (mxg_csr_multiply / add / purge, bit-identical to the host chain).  A host copy of a product is made the first
+    // time somebody asks for one (mxh_sim_op and friends).  MXH_DEVICE_CHAIN=0: the chain is formed on the host, here.
+    const char* dc = getenv("MXH_DEVICE_CHAIN");
+    s->chain_ready = (dc && atoi(dc) == 0) || (box_lo && box_hi);
+    s->ops = s->chain_ready ? s->asmb->waveOps() : s->asmb->singleOps();
     s->mask = s->asmb->usedMask();
     s->setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = s;
@@ -175,8 +180,17 @@ static int exportCsr(const mx::Csr<double>& m, int64_t* nrows, int64_t* ncols, i
   return 0;
 }
 
+// the host chain of a sim created in device-chain mode, on first demand
+void mxh_sim_ensure_chain(mxh_sim* s) {
+  if (s->chain_ready) return;
+  std::map<std::string, mx::Csr<double> > full = s->asmb->waveOps();
+  for (auto& kv : full) if (!s->ops.count(kv.first)) s->ops[kv.first] = std::move(kv.second);
+  s->chain_ready = true;
+}
+
 extern "C" int mxh_sim_op(mxh_sim* s, const char* name, int64_t* nrows, int64_t* ncols, int64_t* nnz,
                           const int64_t** rowptr, const int32_t** colidx, const double** vals) {
+  if (!s->ops.count(name)) mxh_sim_ensure_chain(s);
   auto it = s->ops.find(name);
   if (it == s->ops.end()) {
     mxh_set_error(std::string("MxEMOps::getOp: operator '") + name + "' not found.");
@@ -187,6 +201,7 @@ extern "C" int mxh_sim_op(mxh_sim* s, const char* name, int64_t* nrows, int64_t*
 
 const mx::Csr<double>& mxh_sim_shifted_matrix(mxh_sim* s, double shift) {
   auto it = s->shifted.find(shift);
+  mxh_sim_ensure_chain(s);
   if (it == s->shifted.end())
     it = s->shifted.emplace(shift, mx::add(s->ops.at("vecLapl"), 1.0, s->ops.at("mRhs"), -shift)).first;
   return it->second;
@@ -334,6 +349,7 @@ extern "C" int mxh_sim_dist_op(mxh_sim* s, const char* name, double shift, int64
     const mx::Csr<double>* m;
     if (nm == "shifted") m = &mxh_sim_shifted_matrix(s, shift);
     else {
+      if (!s->ops.count(nm)) mxh_sim_ensure_chain(s);
       auto it = s->ops.find(nm);
       if (it == s->ops.end()) throw std::runtime_error("MxEMOps::getOp: operator '" + nm + "' not found.");
       m = &it->second;

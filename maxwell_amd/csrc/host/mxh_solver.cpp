@@ -205,6 +205,7 @@ extern "C" int mxh_dist_ops_matrix(mxh_dist_ops* d, const char* name, double shi
         m = d->sim->isDistributed() ? d->ops->distributed(b, b, B, B, mxh_sim_shifted_matrix(d->src, shift))
                                     : rcp(new MxCrsMatrix<double>(b, b, mxh_sim_shifted_matrix(d->src, shift)));
       } else {
+        if (!d->src->ops.count(nm)) mxh_sim_ensure_chain(d->src);
         auto op = d->src->ops.find(nm);
         if (op == d->src->ops.end()) throw std::runtime_error("MxEMOps::getOp: operator '" + nm + "' not found.");
         d->ops->adopt(nm, op->second);

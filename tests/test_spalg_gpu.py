@@ -101,3 +101,26 @@ def test_device_algebra_general_matrices(ctx, rng):
     P = mx.CsrMatrix.from_scipy(ctx, A).purge(0.5).to_scipy()
     keep = np.abs(A.data) > 0.5
     assert P.nnz == int(keep.sum()) and np.array_equal(P.data, A.data[keep])
+
+
+def test_eigen_solve_with_the_chain_formed_on_the_device(ctx):
+    """MXH_DEVICE_CHAIN=1: the sim assembles the single operators only, MxMagWaveOp::initMatrices forms curlCurl,
+    gradDiv, vecLapl, scaLapl and the shifted operator through MxCrsMatrix::matrixMatrixMultiply / Add / purgeZeros on
+    the GPU, the multigrid setup reads the finished matrices back.  Same matrices bit for bit, so the whole solve
+    reproduces the host-chain solve exactly.  (The switch is read once per process: the device-chain run is a child.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r); import numpy as np; import maxwell_amd as mx\n"
+            "ctx = mx.Ctx(0); sim = mx.Sim.pillbox(16)\n"
+            "p = mx.SolverParams(nev=4, basis=25, tol=1e-9, shift=1.9739208802178716, lin_type='cg', lin_tol=1e-10, prec_type='amg')\n"
+            "s = mx.Solver(ctx, sim, p); n = s.solve(); st = s.stats()\n"
+            "print('RESULT ' + json.dumps(dict(k2=[s.result(i)['k2'].real for i in range(n)], vec=st['vec_iters'], sca=st['sca_iters'])))\n" % root)
+    outs = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, MXH_DEVICE_CHAIN=mode)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        outs[mode] = json.loads(line[7:])
+    assert len(outs["0"]["k2"]) == 4
+    assert outs["0"] == outs["1"], outs
