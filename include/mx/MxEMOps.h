@@ -30,6 +30,11 @@ class MxEMOps {
       insert("invEps", e, e, a.invEps());
       insert("invEpsVolAve", p, p, a.invEpsVolAve());
     }
+    if (mSim->hasMu()) {                                           // src/MxEMOps.cpp:128-141
+      if (pid == 0) std::cout << "Constructing FIT inverse mu operator...\n";
+      insert("mu", b, b, a.muOp());
+      insert("invMuVolAve", p, p, a.invMuVolAve());
+    }
   }
   RCP<MxCrsMatrix<Scalar> > getOp(std::string name) const {
     auto it = mOps.find(name);
@@ -87,7 +92,7 @@ class MxEMOps {
     else if (name == "divB") { rows = p; }
     else if (name == "gradPsi") { cols = p; }
     else if (name == "dmL" || name == "invEps") { rows = e; cols = e; }
-    else if (name == "dmVInv" || name == "invEpsVolAve" || name == "scaLapl") { rows = p; cols = p; }
+    else if (name == "dmVInv" || name == "invEpsVolAve" || name == "invMuVolAve" || name == "scaLapl") { rows = p; cols = p; }
     if (!mSim->isDistributed()) { mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, m)); return; }
     mOps[name] = distributed(rows, cols, fieldOf(rows, b, e), fieldOf(cols, b, e), m);
   }

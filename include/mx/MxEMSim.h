@@ -93,7 +93,7 @@ class MxEMSim {
   void setComplexAssembler(std::shared_ptr<mx::YeeAssembler<MxComplex> > a) { mAsmC = a; }
   bool hasPEC() const { return (bool)mCfg.pec; }
   bool hasDielectric() const { return !mCfg.dielectrics.empty(); }
-  bool hasMu() const { return false; }
+  bool hasMu() const { return !mCfg.mus.empty(); }
   bool hasPML() const { return false; }
   const MxGrid<DIM>& getGrid() const { return mGrid; }
   Teuchos::ParameterList getParameters() const { return mPList; }

@@ -215,11 +215,15 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true, true, "curlCurl");
     if (mHasCurlNull) {
       names.clear();
+      if (mSim->hasMu()) names.push_back("mu");
       if (mSim->hasPEC()) names.push_back("dmA");
       names.push_back("divB");
       if (mSim->hasPEC()) names.push_back("dmVInv");
+      if (mSim->hasMu()) names.push_back("invMuVolAve");
       if (mSim->hasDielectric()) names.push_back("invEpsVolAve");
+      if (mSim->hasMu()) names.push_back("invMuVolAve");
       names.push_back("gradPsi");
+      if (mSim->hasMu()) names.push_back("mu");
       if (mSim->hasPEC()) names.push_back("dmA");
       mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true, true, "gradDiv");
       names.clear();
@@ -233,6 +237,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
       mVecLapl->purgeZeros();
       names.clear();
       names.push_back("gradPsi");
+      if (mSim->hasMu()) names.push_back("mu");
       if (mSim->hasPEC()) names.push_back("dmA");
       names.push_back("divB");
       mScaLapl = mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true, true, "scaLapl");
@@ -240,7 +245,14 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     } else {
       mVecLapl = mEMOps->getOp("curlCurl");
     }
-    if (mSim->hasPEC()) mRhs = mEMOps->getOp("dmA");
+    if (mSim->hasPEC() && mSim->hasMu()) {                                     // :224-230
+      names.clear();
+      names.push_back("mu");
+      names.push_back("dmA");
+      mRhs = mEMOps->multiplyOps(names, std::vector<bool>(names.size(), false), true);
+    }
+    else if (mSim->hasPEC()) mRhs = mEMOps->getOp("dmA");
+    else if (mSim->hasMu()) mRhs = mEMOps->getOp("mu");
     else mRhs = rcp(new MxCrsMatrix<Scalar>(mBMap, ScalarTraits<Scalar>::one()));
   }
 

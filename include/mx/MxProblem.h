@@ -412,9 +412,10 @@ class MxProblem {
     else if (tag == "PEC") getPEC(node);
     else if (tag == "BoundaryConditions") getBCs(node);
     else if (tag == "Dielectric") getDielectric(node);
-    else if (tag == "Mu" || tag == "PML")
-      throw std::runtime_error("MxProblem: <" + tag + "> blocks are outside the accelerated path of this build "
-                               "(vacuum / PEC / lossless dielectrics, SURVEY §8); refusing to ignore it.");
+    else if (tag == "Mu") getMu(node);
+    else if (tag == "PML")
+      throw std::runtime_error("MxProblem: <PML> blocks are outside the accelerated path of this build "
+                               "(vacuum / PEC / dielectrics / magnetic materials, SURVEY §8); refusing to ignore it.");
     else if (pid == 0)
       std::cout << "MxProblem<" << DIM << ">::parseNode: Did not understand XML tag: '" << tag << "'. Ignoring.\n";
   }
@@ -608,6 +609,30 @@ class MxProblem {
     d.eps[0][2] = d.eps[2][0] = off[1];
     d.eps[1][2] = d.eps[2][1] = off[0];
     cfg.dielectrics.push_back(d);
+  }
+
+  void getMu(XMLNode const& node) {   // src/MxProblem.cpp:515-556
+    using MxUtil::XML::getAttr;
+    int nShapes = 0, first = -1;
+    for (int i = 0; i < node.numChildren(); ++i)
+      if (isShapeTag(node.getChild(i).getTag())) { if (first < 0) first = i; ++nShapes; }
+    if (node.numChildren() > 1 || nShapes != 1)
+      throw std::runtime_error("Mu object should contain exactly 1 Shape object");
+    mx::YeeMu m;
+    m.name = getAttr("name", node, "mu" + std::to_string(cfg.mus.size()));
+    if (pid == 0) std::cout << "Parsed mu object '" << m.name << "'\n";
+    m.shape = shapes[getShape(node.getChild(first))];
+    double diag[3], off[3];
+    mxdetail::strFill(getAttr("mu diag", node, "[1.0, 1.0, 1.0]"), diag, 3, 0.0);
+    mxdetail::strFill(getAttr("mu off diag", node, "[0.0, 0.0, 0.0]"), off, 3, 0.0);
+    if (atof(getAttr("loss tangent", node, "0.0").c_str()) != 0)
+      throw std::runtime_error("MxProblem: a lossy <Mu> (complex permeability) is outside the accelerated path of this build");
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.mu[i][j] = 0.0;
+    for (int i = 0; i < 3; ++i) m.mu[i][i] = diag[i];
+    m.mu[0][1] = m.mu[1][0] = off[2];                                        // :549-551
+    m.mu[0][2] = m.mu[2][0] = off[1];
+    m.mu[1][2] = m.mu[2][1] = off[0];
+    cfg.mus.push_back(m);
   }
 
   void getBCs(XMLNode const& node) {   // src/MxProblem.cpp:604-645

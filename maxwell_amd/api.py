@@ -367,7 +367,7 @@ class Sim:
     """Grid + BCs + PEC shape -> assembled operators (MxEMSim::setup + MxEMOps + initMatrices)."""
 
     def __init__(self, n, origin=(0.0, 0.0, 0.0), size=(1.0, 1.0, 1.0), lower=("periodic",) * 3,
-                 upper=("periodic",) * 3, pec_shape=None, strict=True, dielectrics=None, dm_frac=0.0, box=None):
+                 upper=("periodic",) * 3, pec_shape=None, strict=True, dielectrics=None, dm_frac=0.0, box=None, mus=None):
         """dielectrics: list of (eps, shape_spec[, loss_tangent]); eps = 3 diagonal numbers, or 6 (diag + the
         deck's `eps off diag` triple), or a scalar for an isotropic material.  A loss tangent makes the problem
         complex: its operators come from Problem.op, not from Sim.
@@ -392,6 +392,12 @@ class Sim:
                 e = [float(eps)] * 3 if np.ndim(eps) == 0 else [float(v) for v in eps]
                 items.append(",".join(repr(v) for v in e) + (" tan=%r" % tan if tan else "") + " : " + shape)
             dspec = " | ".join(items).encode()
+        if mus:                    # magnetic materials: list of (mu, shape_spec), mu = scalar, 3 diagonal numbers, or 6
+            items = []
+            for mu, shape in mus:
+                m = [float(mu)] * 3 if np.ndim(mu) == 0 else [float(v) for v in mu]
+                items.append("mu " + ",".join(repr(v) for v in m) + " : " + shape)
+            dspec = ((dspec.decode() + " | ") if dspec else "").encode() + " | ".join(items).encode()
         _chk(self.lib.mxh_sim_create_ex(nn, oo, ss, lo, up, pec_shape.encode() if pec_shape else None, dspec,
                                         float(dm_frac), int(bool(strict)), blo, bhi, C.byref(h)), self.lib, "mxh")
         self.h = h

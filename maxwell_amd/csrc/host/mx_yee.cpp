@@ -86,6 +86,9 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
   Tick tick;
   for (int c = 0; c < 3; ++c)
     for (int i = 0; i < 3; ++i) { D_.xi0[c][i] = E_.xi0[c][i]; D_.lbc[c][i] = E_.lbc[c][i]; D_.ubc[c][i] = E_.ubc[c][i]; }
+  H_.name = "hfield"; H_.ncomp = 3;
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 3; ++i) { H_.xi0[c][i] = B_.xi0[c][i]; H_.lbc[c][i] = B_.lbc[c][i]; H_.ubc[c][i] = B_.ubc[c][i]; }
   const bool diel = !cfg_.dielectrics.empty();
   if (cfg_.pec) {                                              // src/MxEMSim.cpp:121-129
     addShapeRep(B_, *cfg_.pec, B_.frac);
@@ -98,6 +101,13 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
     for (YeeField* F : {&E_, &D_, &P_}) {
       F->dielFrac.emplace_back();
       addShapeRep(*F, *dl.shape, F->dielFrac.back());
+    }
+  }
+  for (const YeeMu& m : cfg_.mus) {                            // src/MxEMSim.cpp:148-163 (not on E, D)
+    if (!m.shape) throw std::runtime_error("YeeAssembler: mu object '" + m.name + "' has no shape");
+    for (YeeField* F : {&B_, &H_, &P_}) {
+      F->muFrac.emplace_back();
+      addShapeRep(*F, *m.shape, F->muFrac.back());
     }
   }
   tick("fractions");
@@ -118,6 +128,9 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
   setMap(P_);
   if (diel) {                                                  // dfield->setMap(efield), src/MxEMSim.cpp:196-197
     D_.gids = E_.gids; D_.wcell = E_.wcell; D_.owned = E_.owned; D_.lidOfWin = E_.lidOfWin;
+  }
+  if (!cfg_.mus.empty()) {                                     // hfield->setMap(bfield), src/MxEMSim.cpp:198-199
+    H_.gids = B_.gids; H_.wcell = B_.wcell; H_.owned = B_.owned; H_.lidOfWin = B_.lidOfWin;
   }
   tick("maps");
 }
@@ -195,7 +208,7 @@ void YeeAssembler<S>::addShapeRep(const YeeField& F, const Shape& shape,
             p[a] = (cfg_.origin[a] + double(ic[a]) * d_[a]) + (F.xi0[comp][a] ? 0.0 : 0.5 * d_[a]);
           double f;
           if (&F == &B_ || &F == &D_) f = rectFraction(shape, p, comp, d_[(comp + 1) % 3], d_[(comp + 2) % 3]);
-          else if (&F == &E_) f = segmentFraction(shape, p, comp, d_[comp]);
+          else if (&F == &E_ || &F == &H_) f = segmentFraction(shape, p, comp, d_[comp]);
           else f = boxFraction(shape, p, d_[0], d_[1], d_[2]);
           fr[extIndex(u)] = f;
         }
@@ -786,6 +799,211 @@ Csr<S> YeeAssembler<S>::invEps() const {
   return m;
 }
 
+template <typename S>
+double YeeAssembler<S>::muFracAt(const YeeField& F, size_t obj, int comp, const int c[3]) const {
+  const int64_t e = extIndex(c);
+  return e < 0 ? 0.0 : F.muFrac[obj][comp][e];
+}
+
+// tupleUpdate of MxYeeFitMu with mInvert = false, src/MxYeeFitMu.cpp:205-290: the averages of the inverse
+// permittivity with H (dual-edge length fractions) and B (face area fractions) in the roles of E and D, multiplied
+// the other way round: avePi * aveGamma^-1 maps the H tuple to the B tuple
+template <typename S>
+void YeeAssembler<S>::muTupleUpdate(const int comps[3], const int cells[3][3], const double n[3],
+                                    double out[3][3]) const {
+  double aveG[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, aveP[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  double lsum[3] = {0, 0, 0}, asum[3] = {0, 0, 0}, gamma[3][3], pi[3][3];
+  for (size_t i = 0; i < cfg_.mus.size(); ++i) {
+    double lf[3] = {0, 0, 0}, af[3] = {0, 0, 0};
+    for (int j = 0; j < 3; ++j) {
+      const int c = comps[j];
+      lf[c] = muFracAt(H_, i, c, cells[j]);
+      af[c] = muFracAt(B_, i, c, cells[j]);
+      lsum[c] += lf[c];
+      asum[c] += af[c];
+    }
+    gammaPi(cfg_.mus[i].mu, n, gamma, pi);
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) { aveG[j][k] += lf[j] * gamma[j][k]; aveP[j][k] += af[j] * pi[j][k]; }
+  }
+  const double bg[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  gammaPi(bg, n, gamma, pi);
+  for (int j = 0; j < 3; ++j) {
+    const double lfj = 1.0 - lsum[j], afj = 1.0 - asum[j];
+    for (int k = 0; k < 3; ++k) { aveG[j][k] += lfj * gamma[j][k]; aveP[j][k] += afj * pi[j][k]; }
+  }
+  double inv[3][3];
+  inverse3(aveG, inv);
+  matmul3(aveP, inv, out);
+}
+
+// getNormal, src/MxYeeFitMu.cpp:134-186
+template <typename S>
+void YeeAssembler<S>::muStencilNormal(int comp0, const int cell[3], const int scomps[9], const int scells[9][3],
+                                      double n[3]) const {
+  Vec3 p;
+  for (int a = 0; a < 3; ++a) p[a] = (cfg_.origin[a] + double(cell[a]) * d_[a]) + (B_.xi0[comp0][a] ? 0.0 : 0.5 * d_[a]);
+  double norms[8][3];
+  int count = 0;
+  for (size_t i = 0; i < cfg_.mus.size() && count < 8; ++i) {
+    bool cut = false;
+    for (int s = 0; s < 9; ++s) {
+      const double lf = muFracAt(H_, i, scomps[s], scells[s]), af = muFracAt(B_, i, scomps[s], scells[s]);
+      if ((lf != 0 && lf != 1) || (af != 0 && af != 1)) cut = true;
+    }
+    if (cut) {
+      const Vec3 g = cfg_.mus[i].shape->gradFunc(p);
+      const double nn = norm(g);
+      for (int k = 0; k < 3; ++k) norms[count][k] = g[k] / nn;
+      ++count;
+    }
+  }
+  if (count == 0) { n[0] = 1.0; n[1] = 0.0; n[2] = 0.0; return; }
+  double tot[3] = {0, 0, 0};
+  for (int i = 0; i < count; ++i) {
+    double sgn = 1.0;
+    if (i > 0 && (norms[0][0] * norms[i][0] + norms[0][1] * norms[i][1] + norms[0][2] * norms[i][2]) < 0) sgn = -1.0;
+    for (int k = 0; k < 3; ++k) tot[k] += sgn * norms[i][k];
+  }
+  const double nn = std::sqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2]);
+  for (int k = 0; k < 3; ++k) n[k] = tot[k] / nn;
+}
+
+// MxYeeFitMu::setMatrix with mInvert = false, src/MxYeeFitMu.cpp:294-463 (3-D, real mu, no PML).  Entries whose
+// column is not in the map are left out (Epetra never imports a value for such a column).
+template <typename S>
+Csr<S> YeeAssembler<S>::muOp() const {
+  const int64_t nrows = (int64_t)B_.gids.size();
+  UVec<int32_t> cols(nrows * 9);
+  UVec<S> vals(nrows * 9);
+  UVec<int32_t> cnt(nrows);
+  static const int tupleInds[8][3] = {{0, 1, 5}, {0, 1, 6}, {0, 2, 5}, {0, 2, 6}, {0, 3, 7}, {0, 3, 8}, {0, 4, 7}, {0, 4, 8}};
+  const size_t nm = cfg_.mus.size();
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int comp0 = (int)(B_.gids[r] % 3);
+    int ucell[3], cell[3];
+    winCell(B_.wcell[r], ucell);
+    canon(ucell, cell);
+    bool inMu = false, muDiag = false;
+    double muHere = 1.0;
+    for (size_t i = 0; i < nm; ++i) {                                         // :333-358
+      const double l0 = muFracAt(H_, i, comp0, cell), a0 = muFracAt(B_, i, comp0, cell);
+      const double (*m)[3] = cfg_.mus[i].mu;
+      if (l0 == 1 && a0 == 1) {
+        inMu = true;
+        muDiag = !(std::abs(m[0][1]) > 0.0 || std::abs(m[0][2]) > 0.0 || std::abs(m[1][2]) > 0.0);   // checkIsDiag, dEps = 0
+        muHere = m[comp0][comp0];
+        break;
+      } else if (l0 == 0 && a0 == 0) {
+        continue;
+      } else {
+        inMu = true;
+        break;
+      }
+    }
+    if (!inMu) { muDiag = true; muHere = 1.0; }
+    int32_t* rc = cols.data() + r * 9;
+    S* rv = vals.data() + r * 9;
+    if (muDiag) {                                                             // :398-409
+      const std::complex<double> fac = factor(B_, comp0, cell);
+      rc[0] = (int32_t)r;
+      rv[0] = toScalar(fac * muHere);
+      cnt[r] = 1;
+      continue;
+    }
+    const int comp1 = (comp0 + 1) % 3, comp2 = (comp0 + 2) % 3;               // getStencil, :27-71
+    int scomps[9] = {comp0, comp1, comp1, comp1, comp1, comp2, comp2, comp2, comp2};
+    int scells[9][3];
+    for (int s = 0; s < 9; ++s) for (int a = 0; a < 3; ++a) scells[s][a] = cell[a];
+    scells[1][comp0] -= 1;
+    scells[2][comp0] -= 1; scells[2][comp1] += 1;
+    scells[4][comp1] += 1;
+    scells[5][comp0] -= 1;
+    scells[6][comp0] -= 1; scells[6][comp2] += 1;
+    scells[8][comp2] += 1;
+    double normal[3];
+    muStencilNormal(comp0, cell, scomps, scells, normal);
+    int use[8], nt = 0;                                                        // getTuples, :75-128
+    for (int t = 0; t < 8; ++t) {
+      bool ok = true;
+      if (cfg_.pec)
+        for (int j = 0; j < 3; ++j) {
+          const int si = tupleInds[t][j];
+          if (fracAt(B_, scomps[si], scells[si]) == 0) ok = false;
+        }
+      if (ok) use[nt++] = t;
+    }
+    double svals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const double ntd = double(nt);
+    for (int u = 0; u < nt; ++u) {                                             // :424-437
+      const int* t = tupleInds[use[u]];
+      int tcomps[3], tcells[3][3];
+      for (int j = 0; j < 3; ++j) { tcomps[j] = scomps[t[j]]; for (int a = 0; a < 3; ++a) tcells[j][a] = scells[t[j]][a]; }
+      double m[3][3];
+      muTupleUpdate(tcomps, tcells, normal, m);
+      for (int j = 0; j < 3; ++j) svals[t[j]] += m[comp0][scomps[t[j]]] / ntd;
+    }
+    int n = 0;
+    for (int s = 0; s < 9; ++s) {                                              // :441-442
+      const std::complex<double> fac = factor(B_, scomps[s], scells[s]);
+      int ic[3];
+      interior(B_, scomps[s], scells[s], ic);
+      const int32_t lid = lidOf(B_, scomps[s], ic);
+      if (lid < 0) continue;
+      rc[n] = lid;
+      rv[n] = S(svals[s]) * toScalar(fac);
+      ++n;
+    }
+    for (int x = 1; x < n; ++x) {   // sort by column, merge repeated columns in insertion order (Epetra FillComplete)
+      const int32_t cc = rc[x]; const S vv = rv[x];
+      int y = x - 1;
+      while (y >= 0 && rc[y] > cc) { rc[y + 1] = rc[y]; rv[y + 1] = rv[y]; --y; }
+      rc[y + 1] = cc; rv[y + 1] = vv;
+    }
+    int w = 0;
+    for (int x = 0; x < n; ++x) {
+      if (w > 0 && rc[w - 1] == rc[x]) rv[w - 1] += rv[x];
+      else { rc[w] = rc[x]; rv[w] = rv[x]; ++w; }
+    }
+    cnt[r] = w;
+  }
+  Csr<S> m;
+  m.nrows = nrows; m.ncols = nrows;
+  m.rowptr.resize(nrows + 1); m.rowptr[0] = 0;
+  for (int64_t r = 0; r < nrows; ++r) m.rowptr[r + 1] = m.rowptr[r] + cnt[r];
+  m.col.resize(m.rowptr[nrows]);
+  m.val.resize(m.rowptr[nrows]);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < nrows; ++r) {
+    std::copy(cols.begin() + r * 9, cols.begin() + r * 9 + cnt[r], m.col.begin() + m.rowptr[r]);
+    std::copy(vals.begin() + r * 9, vals.begin() + r * 9 + cnt[r], m.val.begin() + m.rowptr[r]);
+  }
+  return m;
+}
+
+// cellAveInvMuOperator, src/MxYeeFitMu.cpp:532-600: volume-fraction average of 3/trace(mu) on the Psi map
+template <typename S>
+Csr<S> YeeAssembler<S>::invMuVolAve() const {
+  UVec<S> d(P_.gids.size());
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < (int64_t)P_.gids.size(); ++r) {
+    int ucell[3], cell[3];
+    winCell(P_.wcell[r], ucell);
+    canon(ucell, cell);
+    double out = 0.0, sums = 0.0;
+    for (size_t i = 0; i < cfg_.mus.size(); ++i) {
+      const double fr = muFracAt(P_, i, 0, cell);
+      const double (*m)[3] = cfg_.mus[i].mu;
+      sums = sums + fr;
+      out = out + fr * (3.0 / (m[0][0] + m[1][1] + m[2][2]));
+    }
+    out = out + (1.0 - sums) * (3.0 / 3.0);
+    d[r] = S(out);
+  }
+  return diagonal<S>(d);
+}
+
 // cellAveInvEpsOperator, src/MxYeeFitInvEps.cpp:700-790: volume-fraction average of 3/trace(eps)
 template <typename S>
 Csr<S> YeeAssembler<S>::invEpsVolAve() const {
@@ -858,6 +1076,10 @@ std::map<std::string, Csr<S>> YeeAssembler<S>::singleOps() const {   // MxEMOps:
     o["invEps"] = invEps();
     o["invEpsVolAve"] = invEpsVolAve();
   }
+  if (hasMu()) {                                                           // src/MxEMOps.cpp:128-141
+    o["mu"] = muOp();
+    o["invMuVolAve"] = invMuVolAve();
+  }
   return o;
 }
 
@@ -872,18 +1094,23 @@ std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps() const {   // src/MxMagW
   std::vector<std::string> names;
   names = {"curlB"}; if (diel) names.push_back("invEps"); opt(names, "dmL"); names.push_back("curlE");
   o["curlCurl"] = multiplyOps(o, names);                                   // :145-153
-  names.clear(); opt(names, "dmA"); names.push_back("divB"); opt(names, "dmVInv");
+  const bool mag = hasMu();
+  names.clear(); if (mag) names.push_back("mu"); opt(names, "dmA"); names.push_back("divB"); opt(names, "dmVInv");
+  if (mag) names.push_back("invMuVolAve");
   if (diel) names.push_back("invEpsVolAve");
-  names.push_back("gradPsi"); opt(names, "dmA");
+  if (mag) names.push_back("invMuVolAve");
+  names.push_back("gradPsi"); if (mag) names.push_back("mu"); opt(names, "dmA");
   o["gradDiv"] = multiplyOps(o, names);                                    // :156-179
   tick("products");
   o["vecLapl"] = purge(add(o["curlCurl"], S(1.0), o["gradDiv"], S(-1.0)));  // :183-193
   tick("vecLapl");
-  names = {"gradPsi"}; opt(names, "dmA"); names.push_back("divB");
+  names = {"gradPsi"}; if (mag) names.push_back("mu"); opt(names, "dmA"); names.push_back("divB");
   Csr<S> sl = multiplyOps(o, names);                                       // :208-220
   scaleInPlace(sl, S(-1.0));
   o["scaLapl"] = sl;
-  if (pec) o["mRhs"] = o["dmA"];                                           // :233-236
+  if (pec && mag) o["mRhs"] = multiplyOps(o, {"mu", "dmA"});               // :224-230
+  else if (pec) o["mRhs"] = o["dmA"];                                      // :233-236
+  else if (mag) o["mRhs"] = o["mu"];                                       // :237-238
   else o["mRhs"] = diagonal<S>(UVec<S>(B_.gids.size(), S(1.0)));    // :240-241
   return o;
 }

@@ -46,6 +46,13 @@ struct YeeDielectric {
   }
 };
 
+// <Mu> block (src/MxProblem.cpp:515-556, src/MxMu.cpp): symmetric real permeability tensor of a shape
+struct YeeMu {
+  std::string name;
+  std::shared_ptr<const Shape> shape;
+  double mu[3][3];
+};
+
 struct YeeConfig {
   int n[3] = {16, 16, 16};
   double origin[3] = {0, 0, 0};
@@ -60,6 +67,7 @@ struct YeeConfig {
   bool strict = true;
   double dmFrac = 0.0;   // <PEC> 'D-M frac' (src/MxProblem.cpp:450): B faces below it get factor 0
   std::vector<YeeDielectric> dielectrics;   // in deck order; background is vacuum (src/MxEMSim.cpp:32-33)
+  std::vector<YeeMu> mus;                   // magnetic materials in deck order; background mu = 1
   // Distributed assembly (one GPU per MxGridDomain box, src/MxGrid.cpp:171-193): the cells this
   // rank owns, [boxLo, boxHi) per axis; boxHi[i] < 0 means the whole axis, [0, n+1).  The
   // assembler works on the box grown by `halo` cells wherever the axis is split, so the owned rows
@@ -76,6 +84,7 @@ struct YeeField {
   int lbc[3][3], ubc[3][3];       // CompBc per component and axis
   std::vector<UVec<double>> frac;   // per component over the extended lattice; empty: no region
   std::vector<std::vector<UVec<double>>> dielFrac;   // [dielectric][component]: shape reps that are not a region
+  std::vector<std::vector<UVec<double>>> muFrac;     // [mu object][component]
   UVec<int64_t> gids;             // global ids of the (window-)map entries; ascending on the owned box
   UVec<int32_t> wcell;            // window cell index of every map entry
   UVec<uint8_t> owned;            // 1 if the entry's cell lies in the owned box
@@ -92,6 +101,7 @@ class YeeAssembler {
   const YeeField& psifield() const { return P_; }
   const YeeField& dfield() const { return D_; }
   bool hasDielectric() const { return !cfg_.dielectrics.empty(); }
+  bool hasMu() const { return !cfg_.mus.empty(); }
   bool hasPec() const { return (bool)cfg_.pec; }
   const YeeConfig& config() const { return cfg_; }
   double cellSize(int i) const { return d_[i]; }
@@ -105,6 +115,9 @@ class YeeAssembler {
   // FIT inverse permittivity on the E map and its cell average on the Psi map (src/MxYeeFitInvEps.cpp)
   Csr<S> invEps() const;
   Csr<S> invEpsVolAve() const;
+  // FIT permeability on the B map (H -> B) and the cell average of 1/mu on the Psi map (src/MxYeeFitMu.cpp)
+  Csr<S> muOp() const;
+  Csr<S> invMuVolAve() const;
 
   // name -> matrix: curlE curlB divB gradPsi [dmA dmL dmVInv] curlCurl gradDiv vecLapl scaLapl mRhs
   std::map<std::string, Csr<S>> waveOps() const;
@@ -133,6 +146,7 @@ class YeeAssembler {
   std::complex<double> phase_[3];
   bool complexProblem_;
   YeeField B_, E_, P_, D_;   // D: E's positions and map, represented by the dual faces (src/MxYeeFitDField.cpp:42-52)
+  YeeField H_;               // H: B's positions and map, represented by the dual edges (src/MxYeeFitHField.cpp:37-47)
   UVec<uint8_t> bcellUsed_;  // extended lattice
 
   bool windowed_;
@@ -200,6 +214,9 @@ class YeeAssembler {
   int64_t gid(const YeeField& F, int comp, const int c[3]) const;
   void addShapeRep(const YeeField& F, const Shape& shape, std::vector<UVec<double>>& out) const;
   double dielFracAt(const YeeField& F, size_t diel, int comp, const int c[3]) const;
+  double muFracAt(const YeeField& F, size_t obj, int comp, const int c[3]) const;
+  void muStencilNormal(int comp0, const int cell[3], const int scomps[9], const int scells[9][3], double n[3]) const;
+  void muTupleUpdate(const int comps[3], const int cells[3][3], const double n[3], double out[3][3]) const;
   void stencilNormal(int comp0, const int cell[3], const int scomps[9], const int scells[9][3], double n[3]) const;
   void tupleUpdate(const int comps[3], const int cells[3][3], const double n[3], double out[3][3]) const;
   void tupleUpdateC(const int comps[3], const int cells[3][3], const double n[3], std::complex<double> out[3][3]) const;

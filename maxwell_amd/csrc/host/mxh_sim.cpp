@@ -91,6 +91,7 @@ std::vector<mx::YeeDielectric> mxh_parse_dielectrics(const char* spec) {
     const size_t colon = item.find(':');
     if (colon == std::string::npos) throw std::runtime_error("dielectric '" + item + "': expected 'eps : shape'");
     std::string head = item.substr(0, colon);
+    if (head.find("mu") != std::string::npos) continue;                    // a magnetic material: mxh_parse_mus
     double losstan = 0.0;                                                   // optional "tan=<loss tangent>"
     const size_t tpos = head.find("tan=");
     if (tpos != std::string::npos) { losstan = atof(head.c_str() + tpos + 4); head = head.substr(0, tpos); }
@@ -108,6 +109,40 @@ std::vector<mx::YeeDielectric> mxh_parse_dielectrics(const char* spec) {
     d.shape = mxh_parse_shape(item.substr(colon + 1).c_str());
     if (!d.shape) throw std::runtime_error("dielectric '" + item + "': empty shape");
     out.push_back(d);
+  }
+  return out;
+}
+
+// "mu m11,m22,m33[,o0,o1,o2] : shape-spec" items of the same list -> magnetic materials (<Mu>, src/MxProblem.cpp:515-556)
+std::vector<mx::YeeMu> mxh_parse_mus(const char* spec) {
+  std::vector<mx::YeeMu> out;
+  if (!spec) return out;
+  std::string s(spec);
+  size_t pos = 0;
+  while (pos <= s.size()) {
+    size_t bar = s.find('|', pos);
+    if (bar == std::string::npos) bar = s.size();
+    const std::string item = s.substr(pos, bar - pos);
+    pos = bar + 1;
+    const size_t colon = item.find(':');
+    if (colon == std::string::npos) continue;
+    std::string head = item.substr(0, colon);
+    const size_t mpos = head.find("mu");
+    if (mpos == std::string::npos) continue;
+    const std::vector<double> e = numbers(head.substr(mpos + 2));
+    if (e.size() != 3 && e.size() != 6) throw std::runtime_error("mu object '" + item + "': 3 or 6 permeability numbers");
+    mx::YeeMu m;
+    m.name = "mu" + std::to_string(out.size());                            // src/MxProblem.cpp:522-523
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.mu[i][j] = 0.0;
+    for (int i = 0; i < 3; ++i) m.mu[i][i] = e[(size_t)i];
+    if (e.size() == 6) {                                                   // src/MxProblem.cpp:549-551
+      m.mu[0][1] = m.mu[1][0] = e[5];
+      m.mu[0][2] = m.mu[2][0] = e[4];
+      m.mu[1][2] = m.mu[2][1] = e[3];
+    }
+    m.shape = mxh_parse_shape(item.substr(colon + 1).c_str());
+    if (!m.shape) throw std::runtime_error("mu object '" + item + "': empty shape");
+    out.push_back(m);
   }
   return out;
 }
@@ -140,6 +175,7 @@ extern "C" int mxh_sim_create_ex(const int n[3], const double origin[3], const d
     }
     cfg.pec = mxh_parse_shape(pec_shape);
     cfg.dielectrics = mxh_parse_dielectrics(dielectrics);
+    cfg.mus = mxh_parse_mus(dielectrics);
     cfg.dmFrac = dm_frac;
     cfg.strict = strict != 0;
     if (box_lo && box_hi)

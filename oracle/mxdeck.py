@@ -150,6 +150,7 @@ class Deck:
         self.lower, self.upper, self.phase = ["periodic"] * 3, ["periodic"] * 3, [0.0] * 3
         self.pec, self.dm_frac = None, 0.0
         self.dielectrics = []
+        self.mus = []
         eig = None
         for child in root:
             if child.tag == "Grid":
@@ -175,6 +176,15 @@ class Deck:
                 eps[0, 2] = eps[2, 0] = off[1]
                 eps[1, 2] = eps[2, 1] = off[0]
                 self.dielectrics.append((make_shape([c for c in child if c.tag in SHAPE_TAGS][0]), eps, name))
+            elif child.tag == "Mu":                              # src/MxProblem.cpp:515-556
+                name = get_attr("name", child, "mu%d" % len(self.mus))
+                diag = vec(get_attr("mu diag", child, "[1.0, 1.0, 1.0]"))
+                off = vec(get_attr("mu off diag", child, "[0.0, 0.0, 0.0]"))
+                mu = np.diag(diag)
+                mu[0, 1] = mu[1, 0] = off[2]
+                mu[0, 2] = mu[2, 0] = off[1]
+                mu[1, 2] = mu[2, 1] = off[0]
+                self.mus.append((make_shape([c for c in child if c.tag in SHAPE_TAGS][0]), mu, name))
             elif child.tag == "Eigensolver":
                 eig = child
         self._eigensolver(eig)
@@ -200,7 +210,7 @@ class Deck:
     def sim(self, strict=True):
         return YeeSim(self.n, origin=self.origin, size=self.size, lower=self.lower, upper=self.upper,
                       pec=self.pec, phase_shifts=self.phase, strict=strict, dm_frac=self.dm_frac,
-                      dielectrics=self.dielectrics)
+                      dielectrics=self.dielectrics, mus=self.mus)
 
 
 def load(path):

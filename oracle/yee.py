@@ -62,7 +62,7 @@ class YeeSim:
 
     def __init__(self, N, origin=(0., 0., 0.), size=(1., 1., 1.),
                  lower=("periodic",) * 3, upper=("periodic",) * 3,
-                 pec=None, phase_shifts=(0., 0., 0.), strict=True, dm_frac=0.0, dielectrics=()):
+                 pec=None, phase_shifts=(0., 0., 0.), strict=True, dm_frac=0.0, dielectrics=(), mus=()):
         self.n = np.array([int(N)] * 3 if np.isscalar(N) else [int(x) for x in N])
         self.origin = np.array(origin, dtype=float)
         self.size = np.array(size, dtype=float)
@@ -93,7 +93,14 @@ class YeeSim:
         # (src/MxYeeFitDField.cpp:42-52); only built with dielectrics (src/MxEMSim.cpp:83-88)
         D = _Field("dfield", 3, E.coords.copy(), [0, 1, 2]) if self.dielectrics else None
         self.D = D
-        for F, normal_pec, tang_pec in ((B, ZERO, CONSTANT), (E, CONSTANT, ZERO)) + (((D, CONSTANT, ZERO),) if D else ()):
+        # magnetic materials: (shape, 3x3 real symmetric mu, name), src/MxProblem.cpp:515-556 / MxMu.cpp.  H lives where B
+        # lives (MxYeeMagFieldBase) but is represented by the dual edge through the face centre (src/MxYeeFitHField.cpp:37-47);
+        # only built with mu objects (src/MxEMSim.cpp:95-100)
+        self.mus = [(sh, np.array(mu, dtype=float).reshape(3, 3), name) for sh, mu, name in mus]
+        H = _Field("hfield", 3, B.coords.copy(), [0, 1, 2]) if self.mus else None
+        self.H = H
+        for F, normal_pec, tang_pec in ((B, ZERO, CONSTANT), (E, CONSTANT, ZERO)) + (((D, CONSTANT, ZERO),) if D else ()) + \
+                (((H, ZERO, CONSTANT),) if H else ()):
             for c in range(3):
                 for i in range(3):
                     for bcs, arr in ((lower, F.lbc), (upper, F.ubc)):
@@ -107,18 +114,24 @@ class YeeSim:
             for bcs, arr in ((lower, P.lbc), (upper, P.ubc)):
                 arr[0, i] = {"pec": CONSTANT, "pmc": ZERO, "periodic": PERIODIC}[bcs[i]]
 
-        fields = [F for F in (B, E, D, P) if F is not None]
+        fields = [F for F in (B, E, D, H, P) if F is not None]
         if pec is not None:
             for F in fields:
                 F.frac = self._add_shape_rep(F, pec)            # src/MxEMSim.cpp:121-129 (region)
         for sh, _, name in self.dielectrics:                    # src/MxEMSim.cpp:131-146 (not on B)
             for F in fields:
-                if F is not B:
+                if F is not B and F is not H:
+                    F.reps[name] = self._add_shape_rep(F, sh)
+        for sh, _, name in self.mus:                            # src/MxEMSim.cpp:148-163 (not on E, D)
+            for F in fields:
+                if F is not E and F is not D:
                     F.reps[name] = self._add_shape_rep(F, sh)
         for F in (B, E, P):
             self._set_map(F)
         if D is not None:                                       # dfield->setMap(efield), src/MxEMSim.cpp:196-197
             D.gids, D.comp, D.cells = E.gids, E.comp, E.cells
+        if H is not None:                                       # hfield->setMap(bfield), src/MxEMSim.cpp:198-199
+            H.gids, H.comp, H.cells = B.gids, B.comp, B.cells
 
     # ---------------------------------------------------------------- lattice helpers
     def node_coord(self, cells):
@@ -194,7 +207,7 @@ class YeeSim:
             if F is self.B or F is self.D:      # face / dual face normal to the component
                 c1, c2 = (comp + 1) % 3, (comp + 2) % 3
                 fr = geo.rect_fractions(shape, pos, comp, self.d[c1], self.d[c2])
-            elif F is self.E:
+            elif F is self.E or (self.H is not None and F is self.H):
                 fr = geo.segment_fractions(shape, pos, comp, self.d[comp])
             else:
                 fr = geo.box_fractions(shape, pos, self.d[0], self.d[1], self.d[2])
@@ -638,6 +651,151 @@ class YeeSim:
         nn = math.sqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2])
         return [tot[0] / nn, tot[1] / nn, tot[2] / nn]
 
+    def _mu_tuple_update(self, comps, cells, normal):
+        """tupleUpdate of MxYeeFitMu with mInvert = false, src/MxYeeFitMu.cpp:205-290: the inverse-permittivity averages
+        with H (dual-edge length fractions) and B (face area fractions) in the roles of E and D, and the product the
+        other way round: avePi * aveGamma^-1 maps the H tuple to the B tuple."""
+        ave_g = [[0.0] * 3 for _ in range(3)]
+        ave_p = [[0.0] * 3 for _ in range(3)]
+        lsum, asum = [0.0] * 3, [0.0] * 3
+        bg = [[1.0 if i == j else 0.0 for j in range(3)] for i in range(3)]
+        for sh, mu, name in self.mus:
+            lf, af = [0.0] * 3, [0.0] * 3
+            for j in range(3):
+                c = comps[j]
+                cell = np.array(cells[j])
+                lf[c] = float(self.frac_at(self.H, c, cell, name))
+                af[c] = float(self.frac_at(self.B, c, cell, name))
+                lsum[c] += lf[c]
+                asum[c] += af[c]
+            gamma, pi = self._gamma_pi(mu.tolist(), normal)
+            for j in range(3):
+                for k in range(3):
+                    ave_g[j][k] += lf[j] * gamma[j][k]
+                    ave_p[j][k] += af[j] * pi[j][k]
+        gamma, pi = self._gamma_pi(bg, normal)
+        for j in range(3):
+            lfj, afj = 1.0 - lsum[j], 1.0 - asum[j]
+            for k in range(3):
+                ave_g[j][k] += lfj * gamma[j][k]
+                ave_p[j][k] += afj * pi[j][k]
+        return geo._matmul3(ave_p, geo._inverse3(ave_g))
+
+    def mu_op(self):
+        """MxYeeFitMu::setMatrix with mInvert = false, src/MxYeeFitMu.cpp:294-463 (3-D, real mu, no PML): rows and
+        columns on the B map; mu_cc on rows wholly inside one (diagonal) material, otherwise the 9-point stencil of
+        getStencil (:27-71) averaged over the admissible tuples.  Columns that are not in the map are left out."""
+        B, H = self.B, self.H
+        rows, cols, vals = [], [], []
+        tuple_inds = [(0, 1, 5), (0, 1, 6), (0, 2, 5), (0, 2, 6), (0, 3, 7), (0, 3, 8), (0, 4, 7), (0, 4, 8)]
+        names = [name for _, _, name in self.mus]
+        lf0 = {nm: np.empty(len(B.gids)) for nm in names}
+        af0 = {nm: np.empty(len(B.gids)) for nm in names}
+        for c in range(3):
+            sel = B.comp == c
+            for nm in names:
+                lf0[nm][sel] = self.frac_at(H, c, B.cells[sel], nm)
+                af0[nm][sel] = self.frac_at(B, c, B.cells[sel], nm)
+        for r in range(len(B.gids)):
+            comp0 = int(B.comp[r]); cell = B.cells[r]
+            in_mu, mu_diag, mu_here = False, False, None
+            for sh, mu, nm in self.mus:                                 # :333-358
+                l0, a0 = lf0[nm][r], af0[nm][r]
+                if l0 == 1 and a0 == 1:
+                    in_mu, mu_diag, mu_here = True, self._eps_is_diag(mu), mu
+                    break
+                elif l0 == 0 and a0 == 0:
+                    continue
+                else:
+                    in_mu = True
+                    break
+            if not in_mu:
+                mu_diag, mu_here = True, np.eye(3)
+            if mu_diag:                                                 # :398-409
+                fac = self.factor(B, comp0, cell[None, :])[0]
+                rows.append(r); cols.append(r); vals.append(complex(fac) * float(mu_here[comp0, comp0]))
+                continue
+            comp1, comp2 = (comp0 + 1) % 3, (comp0 + 2) % 3            # getStencil, :27-71
+            scomps = [comp0] + [comp1] * 4 + [comp2] * 4
+            scells = [cell.copy() for _ in range(9)]
+            scells[1][comp0] -= 1
+            scells[2][comp0] -= 1; scells[2][comp1] += 1
+            scells[4][comp1] += 1
+            scells[5][comp0] -= 1
+            scells[6][comp0] -= 1; scells[6][comp2] += 1
+            scells[8][comp2] += 1
+            normal = self._mu_stencil_normal(comp0, cell, scomps, scells)
+            tuples = []                                                 # getTuples, :75-128
+            for t in tuple_inds:
+                ok = True
+                if self.pec is not None:
+                    for si in t:
+                        if float(self.frac_at(B, scomps[si], scells[si])) == 0:
+                            ok = False
+                if ok:
+                    tuples.append(t)
+            svals = [0.0] * 9
+            nt = float(len(tuples))
+            for t in tuples:                                            # :424-437
+                tc, tl = [scomps[si] for si in t], [scells[si] for si in t]
+                m = self._mu_tuple_update(tc, tl, normal)
+                for si in t:
+                    svals[si] += m[comp0][scomps[si]] / nt
+            for si in range(9):                                         # :441-442
+                fac = complex(self.factor(B, scomps[si], scells[si][None, :])[0])
+                g = self.gid(B, scomps[si], scells[si][None, :])
+                pos, ok = self.lid(B, g)
+                if ok[0]:
+                    rows.append(r); cols.append(int(pos[0])); vals.append(svals[si] * fac)
+        n = len(B.gids)
+        vals = np.array(vals, dtype=complex)
+        if not self.is_complex:
+            vals = vals.real
+        m = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+        m.sum_duplicates(); m.sort_indices()
+        return m
+
+    def _mu_stencil_normal(self, comp0, cell, scomps, scells):
+        """getNormal, src/MxYeeFitMu.cpp:134-186: as for the dielectrics, with the mu objects and the H / B fractions,
+        taken at the row's face centre."""
+        import math
+        norms = []
+        coord = self.comp_coord(self.B, comp0, cell)
+        for sh, mu, nm in self.mus:
+            cut = False
+            for c, cl in zip(scomps, scells):
+                lf = float(self.frac_at(self.H, c, cl, nm)); af = float(self.frac_at(self.B, c, cl, nm))
+                if (lf != 0 and lf != 1) or (af != 0 and af != 1):
+                    cut = True
+            if cut:
+                g = sh.grad1((float(coord[0]), float(coord[1]), float(coord[2])))
+                nn = math.sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2])
+                norms.append([g[0] / nn, g[1] / nn, g[2] / nn])
+        if not norms:
+            return [1.0, 0.0, 0.0]
+        tot = [0.0, 0.0, 0.0]
+        for i, v in enumerate(norms):
+            sgn = 1.0
+            if i > 0 and (norms[0][0] * v[0] + norms[0][1] * v[1] + norms[0][2] * v[2]) < 0:
+                sgn = -1.0
+            for k in range(3):
+                tot[k] += sgn * v[k]
+        nn = math.sqrt(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2])
+        return [tot[0] / nn, tot[1] / nn, tot[2] / nn]
+
+    def inv_mu_vol_ave(self):
+        """cellAveInvMuOperator, src/MxYeeFitMu.cpp:532-600: volume-fraction average of 3/trace(mu) on the Psi map."""
+        P = self.P
+        out = np.zeros(len(P.gids)); sums = np.zeros(len(P.gids))
+        for sh, mu, nm in self.mus:
+            fr = self.frac_at(P, 0, P.cells, nm)
+            sums = sums + fr
+            out = out + fr * (3.0 / (mu[0, 0] + mu[1, 1] + mu[2, 2]))
+        out = out + (1.0 - sums) * (3.0 / 3.0)
+        if self.is_complex:
+            out = out.astype(complex)
+        return sp.diags(out, format="csr")
+
     def inv_eps_vol_ave(self):
         """cellAveInvEpsOperator, src/MxYeeFitInvEps.cpp:700-790: volume-fraction average of
         3/trace(eps) on the Psi map (diagonal)."""
@@ -678,6 +836,9 @@ class YeeSim:
         if self.dielectrics:                                   # src/MxEMOps.cpp:66-77
             ops["invEps"] = self.inv_eps()
             ops["invEpsVolAve"] = self.inv_eps_vol_ave()
+        if self.mus:                                           # src/MxEMOps.cpp:128-141
+            ops["mu"] = self.mu_op()
+            ops["invMuVolAve"] = self.inv_mu_vol_ave()
         return ops
 
     @staticmethod
@@ -698,12 +859,17 @@ class YeeSim:
         has_pec = self.pec is not None
         pec = lambda name: [name] if has_pec else []
         diel = lambda name: [name] if self.dielectrics else []
+        mag = lambda name: [name] if self.mus else []
         curlcurl = self.multiply_ops(o, ["curlB"] + diel("invEps") + pec("dmL") + ["curlE"])   # :145-153
-        graddiv = self.multiply_ops(o, pec("dmA") + ["divB"] + pec("dmVInv") + diel("invEpsVolAve") +
-                                    ["gradPsi"] + pec("dmA"))                                 # :156-179
-        scalapl = -self.multiply_ops(o, ["gradPsi"] + pec("dmA") + ["divB"])                # :208-220
-        if has_pec:
+        graddiv = self.multiply_ops(o, mag("mu") + pec("dmA") + ["divB"] + pec("dmVInv") + mag("invMuVolAve") +
+                                    diel("invEpsVolAve") + mag("invMuVolAve") + ["gradPsi"] + mag("mu") + pec("dmA"))  # :156-179
+        scalapl = -self.multiply_ops(o, ["gradPsi"] + mag("mu") + pec("dmA") + ["divB"])    # :208-220
+        if has_pec and self.mus:
+            rhs = self.multiply_ops(o, ["mu", "dmA"])                                       # :224-230
+        elif has_pec:
             rhs = o["dmA"]                                                                  # :233-236
+        elif self.mus:
+            rhs = o["mu"]                                                                   # :237-238
         else:
             rhs = sp.identity(len(self.B.gids), format="csr",
                               dtype=complex if self.is_complex else float)                 # :240-241

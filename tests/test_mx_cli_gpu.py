@@ -133,9 +133,9 @@ def test_maxwell_cli_errors(built, tmp_path):
     r = subprocess.run([CLI], capture_output=True, text=True, timeout=60)
     assert "Please specify an input file using --infile=your_file.mx" in r.stdout
     bad = tmp_path / "bad.mx"
-    bad.write_text("<S>\n polarization = TE\n <Mu>\n </Mu>\n</S>\n")
+    bad.write_text("<S>\n polarization = TE\n <PML>\n </PML>\n</S>\n")
     r = subprocess.run([CLI, "--infile=" + str(bad)], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and "<Mu>" in r.stdout
+    assert r.returncode == 1 and "<PML>" in r.stdout
 
 
 def test_transformed_cavity_deck_through_the_c_abi(ctx):
@@ -186,6 +186,25 @@ def test_dielectric_sphere_deck_non_hermitian(ctx):
     k = np.sqrt(k2)
     assert abs(k[0] - 2.7914257502896397024) / 2.7914 < 5e-3       # TM_11, O(h^2) at resolution 12
     assert abs(k[1] - 4.0593020005144315490) / 4.0593 < 1e-2       # TE_21
+
+
+def test_magnetic_sphere_deck(ctx):
+    """tests/golden/magsph.mx: anisotropic <Mu> sphere around an eps core in a PEC sphere - the FIT permeability
+    operator in the chain (mu dmA divB ... , mRhs = mu dmA; src/MxMagWaveOp.cpp:156-239), non-Hermitian Krylov-Schur
+    (src/MxSolver.cpp:57: hasMu -> not Hermitian).  Against the oracle's dense restatement of the iterated operator,
+    with the operator chain formed on the device (default) and on the host."""
+    name = os.path.join(GOLDEN, "magsph.mx")
+    deck = mxdeck.load(name)
+    want = _oracle_modes(deck, 3)
+    solver = mx.Problem(path=name).solver(ctx)
+    assert solver.solve() == 3
+    res = [solver.result(i) for i in range(3)]
+    k2 = np.sort([r["k2"].real for r in res])
+    assert np.abs(k2 - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (k2, want)
+    assert all(abs(r["k2"].imag) < 1e-9 for r in res)
+    # the empty cavity's lowest mode is k^2 = (2.7437 / 0.49)^2 = 31.4 (TM_11 of a PEC sphere): the magnetic
+    # filling pulls it down
+    assert k2[0] < 0.6 * (2.743707269992265 / 0.49) ** 2
 
 
 def test_complex_decks_bloch_phase_shifts(ctx):
