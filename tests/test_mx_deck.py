@@ -130,6 +130,24 @@ def test_assembled_operators_bit_identical(name):
         assert a.shape == b.shape and (d.nnz == 0 or np.abs(d.data).max() == 0.0), opname
 
 
+def test_mu_stencil_rows_on_wall_faces_keep_their_entries():
+    """The reference multiplies the 9-point mu stencil by the factors of its COLUMNS (src/MxYeeFitMu.cpp:441-442),
+    not of its row: where a non-diagonal <Mu> reaches a PMC/PEC wall, rows of wall faces whose own factor is 0 keep
+    off-diagonal entries (their columns stay empty).  Reproduced bit for bit - it is the reference's matrix - and
+    recorded in DESIGN.md section 7; tests/golden/magsph.mx keeps the magnetic sphere clear of the walls."""
+    text = _text("magsph.mx").replace("origin = [-0.5, -0.5, -0.5]", "origin = [0.0, 0.0, 0.0]").replace(
+        "dimensions = [1.0, 1.0, 1.0]", "dimensions = [0.5, 0.5, 0.5]").replace(
+        "lower bcs = [pec, pec, pec]", "lower bcs = [pmc, pmc, pec]").replace("vector = [0.06, -0.04, 0.03]", "vector = [0.0, 0.0, 0.0]")
+    ops = mxdeck.Deck(text).sim().wave_ops()
+    sim = mx.Problem(text=text).sim()
+    for opname, ref in ops.items():
+        d = sim.op(opname).tocsr() - ref.tocsr()
+        assert d.nnz == 0 or np.abs(d.data).max() == 0.0, opname
+    m = sim.op("mRhs").tocsr()
+    unused = sim.used_mask() == 0
+    assert (np.abs(m).sum(axis=1).A1[unused] > 0).sum() > 10 and np.abs(m).sum(axis=0).A1[unused].max() == 0.0
+
+
 def test_dm_frac_zeroes_small_faces():
     """<PEC> 'D-M frac' (src/MxYeeFitBField.cpp:83-90): B faces below the threshold get factor 0 -
     the map is unchanged, curlE rows of those faces vanish."""
