@@ -25,12 +25,12 @@ class MxEMOps {
     insert("divB", p, b, a.divB());
     insert("gradPsi", b, p, a.gradPsi());
     if (mSim->hasPEC()) insert("dmVInv", p, p, a.fracs(a.psifield(), true));
-    if (mSim->hasDielectric()) {                                   // src/MxEMOps.cpp:66-77
+    if (mSim->hasDielectric() || mSim->hasPML()) {                 // src/MxEMOps.cpp:66-77
       if (pid == 0) std::cout << "Constructing FIT inverse epsilon operator...\n";
       insert("invEps", e, e, a.invEps());
       insert("invEpsVolAve", p, p, a.invEpsVolAve());
     }
-    if (mSim->hasMu()) {                                           // src/MxEMOps.cpp:128-141
+    if (mSim->hasMu() || mSim->hasPML()) {                         // src/MxEMOps.cpp:128-141
       if (pid == 0) std::cout << "Constructing FIT inverse mu operator...\n";
       insert("mu", b, b, a.muOp());
       insert("invMuVolAve", p, p, a.invMuVolAve());

@@ -68,6 +68,7 @@ class MxEMSim {
     static_assert(DIM == 3, "only the 3-D path is built");
     mComplex = cfg.phaseShifts[0] != 0.0 || cfg.phaseShifts[1] != 0.0 || cfg.phaseShifts[2] != 0.0;
     for (auto const& dl : cfg.dielectrics) if (dl.lossy()) mComplex = true;   // loss tangent, src/MxProblem.cpp:507-508
+    if (!cfg.pmls.empty()) mComplex = true;                                   // src/MxProblem.cpp:596-597
     if (mComplex) {
       mAsmC = complexAssembler ? complexAssembler : std::make_shared<mx::YeeAssembler<MxComplex> >(cfg);
       addFields(*mAsmC, comm);
@@ -94,7 +95,7 @@ class MxEMSim {
   bool hasPEC() const { return (bool)mCfg.pec; }
   bool hasDielectric() const { return !mCfg.dielectrics.empty(); }
   bool hasMu() const { return !mCfg.mus.empty(); }
-  bool hasPML() const { return false; }
+  bool hasPML() const { return !mCfg.pmls.empty(); }
   const MxGrid<DIM>& getGrid() const { return mGrid; }
   Teuchos::ParameterList getParameters() const { return mPList; }
   void setParameters(Teuchos::ParameterList p) { mPList = p; mPList.set("has curl null", true); }
@@ -136,7 +137,7 @@ class MxEMSim {
     addField("bfield", a.bfield(), a.usedMask(), comm);
     addField("efield", a.efield(), std::vector<double>(), comm);
     addField("psifield", a.psifield(), std::vector<double>(), comm);
-    if (hasDielectric()) mFields["dfield"] = mFields["efield"];   // dfield->setMap(efield), src/MxEMSim.cpp:196-197
+    if (hasDielectric() || hasPML()) mFields["dfield"] = mFields["efield"];   // dfield->setMap(efield), src/MxEMSim.cpp:196-197
   }
   void addField(const char* name, const mx::YeeField& f, std::vector<double> mask, RCP<MxComm> comm) {
     std::vector<MxIndex> g;

@@ -413,9 +413,7 @@ class MxProblem {
     else if (tag == "BoundaryConditions") getBCs(node);
     else if (tag == "Dielectric") getDielectric(node);
     else if (tag == "Mu") getMu(node);
-    else if (tag == "PML")
-      throw std::runtime_error("MxProblem: <PML> blocks are outside the accelerated path of this build "
-                               "(vacuum / PEC / dielectrics / magnetic materials, SURVEY §8); refusing to ignore it.");
+    else if (tag == "PML") getPML(node);
     else if (pid == 0)
       std::cout << "MxProblem<" << DIM << ">::parseNode: Did not understand XML tag: '" << tag << "'. Ignoring.\n";
   }
@@ -633,6 +631,21 @@ class MxProblem {
     m.mu[0][2] = m.mu[2][0] = off[1];
     m.mu[1][2] = m.mu[2][1] = off[0];
     cfg.mus.push_back(m);
+  }
+
+  void getPML(XMLNode const& node) {   // src/MxProblem.cpp:559-598
+    using MxUtil::XML::getAttr;
+    if (node.numChildren() > 1) throw std::runtime_error("PML object should contain no more than 1 Shape object");
+    if (node.numChildren() == 0) throw std::runtime_error("PML object needs to contain exactly 1 Shape object");
+    mx::YeePml m;
+    m.name = getAttr("name", node, "PML" + std::to_string(cfg.pmls.size()));
+    m.shape = shapes[getShape(node.getChild(0))];
+    m.alphaMax = atof(getAttr("max alpha", node, "1.0").c_str());
+    m.exponent = atof(getAttr("exponent", node, "2.0").c_str());
+    mxdetail::strFill(getAttr("profile begin", node), m.begin, 3, 0.0);       // required attributes
+    mxdetail::strFill(getAttr("profile end", node), m.end, 3, 0.0);
+    cfg.pmls.push_back(m);
+    pList.set("is complex", true);                                            // :596-597
   }
 
   void getBCs(XMLNode const& node) {   // src/MxProblem.cpp:604-645

@@ -55,7 +55,12 @@ class MxSolver {
     mEigProb = rcp(new Anasazi::BasicEigenproblem<Scalar, MV, OP>(op, mInitVec));
     mEigProb->setNEV(nev);
     if (!sim->hasDielectric() && !sim->hasMu()) mEigProb->setHermitian(true);
-    mEigProb->setM(rcp<OP>(new MxMassOp<Scalar>(mwOp->getRhs())));
+    // The reference iterates in the Euclidean inner product (src/MxSolver.cpp:69-75 never calls setM).  With mRhs = dmA
+    // (or I) - a real positive diagonal - the shift-inverted operator is self-adjoint in the mRhs inner product when
+    // there are no materials, which is what the Hermitian Krylov-Schur path needs; that inner product is kept for the
+    // dielectric case too.  With a <Mu> object mRhs = mu dmA is neither diagonal nor (with a PML) Hermitian, x^H mRhs y
+    // is not an inner product any more, and the solver works in the Euclidean one as the reference does.
+    if (!sim->hasMu()) mEigProb->setM(rcp<OP>(new MxMassOp<Scalar>(mwOp->getRhs())));
     if (!mEigProb->setProblem() && myPID == 0)
       std::cout << "Anasazi::BasicEigenproblem::setProblem() returned with error." << std::endl;
     if (type == "krylov-schur" || type == "davidson") {

@@ -41,9 +41,24 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
     if (cfg.phaseShifts[i] != 0.0) complexProblem_ = true;
   }
   for (const YeeDielectric& dl : cfg.dielectrics) if (dl.lossy()) lossy_ = true;
+  for (const YeePml& pm : cfg.pmls) {                             // MxPML::setProfileEndpoints, src/MxPML.h:107-115
+    if (!pm.shape) throw std::runtime_error("YeeAssembler: PML '" + pm.name + "' has no shape");
+    PmlGeom g;
+    double dd[3];
+    for (int i = 0; i < 3; ++i) dd[i] = pm.end[i] - pm.begin[i];
+    g.width = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+    for (int i = 0; i < 3; ++i) g.dir[i] = dd[i] / g.width;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        g.outer[i][j] = std::complex<double>(g.dir[i] * g.dir[j], 0.0);      // (a, 0)(b, 0): setOuterProds, :85-92
+        g.compl_[i][j] = std::complex<double>(i == j ? 1.0 : 0.0, 0.0) - g.outer[i][j];
+      }
+    pmlGeom_.push_back(g);
+    lossy_ = true;
+  }
   if (lossy_) complexProblem_ = true;
   if (complexProblem_ && sizeof(S) == sizeof(double))
-    throw std::runtime_error("phase shifts / lossy dielectrics need the complex assembler");
+    throw std::runtime_error("phase shifts / lossy dielectrics / PMLs need the complex assembler");
   B_.name = "bfield"; E_.name = "efield"; P_.name = "psifield"; D_.name = "dfield";
   B_.ncomp = 3; E_.ncomp = 3; P_.ncomp = 1; D_.ncomp = 3;
   for (int c = 0; c < 3; ++c)
@@ -89,7 +104,7 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
   H_.name = "hfield"; H_.ncomp = 3;
   for (int c = 0; c < 3; ++c)
     for (int i = 0; i < 3; ++i) { H_.xi0[c][i] = B_.xi0[c][i]; H_.lbc[c][i] = B_.lbc[c][i]; H_.ubc[c][i] = B_.ubc[c][i]; }
-  const bool diel = !cfg_.dielectrics.empty();
+  const bool diel = !cfg_.dielectrics.empty() || !cfg_.pmls.empty();   // src/MxEMSim.cpp:89
   if (cfg_.pec) {                                              // src/MxEMSim.cpp:121-129
     addShapeRep(B_, *cfg_.pec, B_.frac);
     addShapeRep(E_, *cfg_.pec, E_.frac);
@@ -129,7 +144,7 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
   if (diel) {                                                  // dfield->setMap(efield), src/MxEMSim.cpp:196-197
     D_.gids = E_.gids; D_.wcell = E_.wcell; D_.owned = E_.owned; D_.lidOfWin = E_.lidOfWin;
   }
-  if (!cfg_.mus.empty()) {                                     // hfield->setMap(bfield), src/MxEMSim.cpp:198-199
+  if (!cfg_.mus.empty() || !cfg_.pmls.empty()) {               // hfield->setMap(bfield), src/MxEMSim.cpp:96,198-199
     H_.gids = B_.gids; H_.wcell = B_.wcell; H_.owned = B_.owned; H_.lidOfWin = B_.lidOfWin;
   }
   tick("maps");
@@ -605,7 +620,88 @@ void gammaPiC(const Cx eps[3][3], const double n[3], Cx gamma[3][3], Cx pi[3][3]
   matmul3c(eps, gamma, pi);
 }
 
+Cx det3c(const Cx m[3][3]) {   // det(MxDimMatrix<T, 3>), src/MxDimMatrix.hpp:376-384
+  return cmul(cmul(m[0][0], m[1][1]), m[2][2]) + cmul(cmul(m[0][1], m[1][2]), m[2][0]) + cmul(cmul(m[0][2], m[1][0]), m[2][1]) -
+         cmul(cmul(m[0][2], m[1][1]), m[2][0]) - cmul(cmul(m[0][1], m[1][0]), m[2][2]) - cmul(cmul(m[0][0], m[1][2]), m[2][1]);
+}
+// (T m T) / det, the matrix / scalar quotient as m * (1 / det) (src/MxDimMatrix.hpp:152-154)
+void pmlSandwich(const Cx t[3][3], const Cx& det, Cx m[3][3]) {
+  Cx a[3][3], b[3][3];
+  matmul3c(t, m, a);
+  matmul3c(a, t, b);
+  const Cx inv = cdiv(Cx(1.0, 0.0), det);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = cmul(inv, b[i][j]);
+}
+
 }  // namespace
+
+template <typename S>
+void YeeAssembler<S>::compCoord(const YeeField& F, int comp, const int cell[3], double p[3]) const {
+  for (int a = 0; a < 3; ++a) p[a] = (cfg_.origin[a] + double(cell[a]) * d_[a]) + (F.xi0[comp][a] ? 0.0 : 0.5 * d_[a]);
+}
+
+// src/MxYeeFitInvEps.cpp:514-537 / src/MxYeeFitMu.cpp:385-410.  MxPML::isDiag() is false for every layer (setIsDiag
+// counts |dir_i| < MxUtil::dEps with dEps = 0.0, src/MxUtil.hpp:26), so a row inside any layer takes the stencil path.
+template <typename S>
+bool YeeAssembler<S>::pmlTransform(const double p[3], bool inverse, Cx t[3][3], Cx& det) const {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t[i][j] = Cx(i == j ? 1.0 : 0.0, 0.0);
+  bool diag = true;
+  Vec3 q; q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+  for (size_t l = 0; l < cfg_.pmls.size(); ++l) {
+    const YeePml& pm = cfg_.pmls[l];
+    if (!(pm.shape->func(q) > 0)) continue;
+    diag = false;
+    const PmlGeom& g = pmlGeom_[l];
+    const double tt = ((p[0] - pm.begin[0]) * g.dir[0] + (p[1] - pm.begin[1]) * g.dir[1] + (p[2] - pm.begin[2]) * g.dir[2]) / g.width;
+    const Cx sv(1.0, pm.alphaMax * std::pow(tt, pm.exponent));               // getAlpha, src/MxPML.h:168-171
+    const Cx f = inverse ? sv : cdiv(Cx(1.0, 0.0), sv);                      // getInvS :145-149 / getS :151-161
+    Cx m[3][3], r[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = cmul(f, g.outer[i][j]) + g.compl_[i][j];
+    matmul3c(t, m, r);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t[i][j] = r[i][j];
+  }
+  det = det3c(t);
+  return diag;
+}
+
+// tupleUpdate of MxYeeFitMu in complex arithmetic (used with PMLs)
+template <typename S>
+void YeeAssembler<S>::muTupleUpdateC(const int comps[3], const int cells[3][3], const double n[3], Cx out[3][3]) const {
+  Cx aveG[3][3], aveP[3][3], gamma[3][3], pi[3][3];
+  for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) { aveG[j][k] = Cx(0.0, 0.0); aveP[j][k] = Cx(0.0, 0.0); }
+  double lsum[3] = {0, 0, 0}, asum[3] = {0, 0, 0};
+  for (size_t i = 0; i < cfg_.mus.size(); ++i) {
+    double lf[3] = {0, 0, 0}, af[3] = {0, 0, 0};
+    for (int j = 0; j < 3; ++j) {
+      const int c = comps[j];
+      lf[c] = muFracAt(H_, i, c, cells[j]);
+      af[c] = muFracAt(B_, i, c, cells[j]);
+      lsum[c] += lf[c];
+      asum[c] += af[c];
+    }
+    Cx mu[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) mu[a][b] = Cx(cfg_.mus[i].mu[a][b], 0.0);
+    gammaPiC(mu, n, gamma, pi);
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) {
+        aveG[j][k] = aveG[j][k] + cmul(Cx(lf[j], 0.0), gamma[j][k]);
+        aveP[j][k] = aveP[j][k] + cmul(Cx(af[j], 0.0), pi[j][k]);
+      }
+  }
+  Cx bg[3][3];
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) bg[a][b] = Cx(a == b ? 1.0 : 0.0, 0.0);
+  gammaPiC(bg, n, gamma, pi);
+  for (int j = 0; j < 3; ++j) {
+    const double lfj = 1.0 - lsum[j], afj = 1.0 - asum[j];
+    for (int k = 0; k < 3; ++k) {
+      aveG[j][k] = aveG[j][k] + cmul(Cx(lfj, 0.0), gamma[j][k]);
+      aveP[j][k] = aveP[j][k] + cmul(Cx(afj, 0.0), pi[j][k]);
+    }
+  }
+  Cx inv[3][3];
+  inverse3c(aveG, inv);
+  matmul3c(aveP, inv, out);
+}
 
 // tupleUpdate for complex permittivity (loss tangent)
 template <typename S>
@@ -714,10 +810,19 @@ Csr<S> YeeAssembler<S>::invEps() const {
     if (!inDiel) { epsDiag = true; epsHere = std::complex<double>(1.0, 0.0); }
     int32_t* rc = cols.data() + r * 9;
     S* rv = vals.data() + r * 9;
-    if (epsDiag) {                                                           // :505-512
+    const bool pml = hasPml();
+    bool pmlDiag = true;
+    Cx tr[3][3], det(1.0, 0.0);
+    if (pml) {                                                               // :514-537
+      double pc[3];
+      compCoord(E_, comp0, cell, pc);
+      pmlDiag = pmlTransform(pc, true, tr, det);
+    }
+    if (epsDiag && pmlDiag) {                                                // :542-549
       const std::complex<double> fac = factor(D_, comp0, cell);
       rc[0] = (int32_t)r;
-      rv[0] = toScalar(lossy_ ? cdiv(fac, epsHere) : fac / epsHere.real());
+      if (pml) rv[0] = toScalar(cdiv(cdiv(cmul(cmul(fac, tr[comp0][comp0]), tr[comp0][comp0]), det), epsHere));
+      else rv[0] = toScalar(lossy_ ? cdiv(fac, epsHere) : fac / epsHere.real());
       cnt[r] = 1;
       continue;
     }
@@ -753,6 +858,7 @@ Csr<S> YeeAssembler<S>::invEps() const {
       if (lossy_) {
         std::complex<double> m[3][3];
         tupleUpdateC(tcomps, tcells, normal, m);
+        if (pml) pmlSandwich(tr, det, m);                                     // :567
         for (int j = 0; j < 3; ++j) svalsC[t[j]] = svalsC[t[j]] + m[comp0][scomps[t[j]]] / ntd;
       } else {
         double m[3][3];
@@ -905,10 +1011,20 @@ Csr<S> YeeAssembler<S>::muOp() const {
     if (!inMu) { muDiag = true; muHere = 1.0; }
     int32_t* rc = cols.data() + r * 9;
     S* rv = vals.data() + r * 9;
-    if (muDiag) {                                                             // :398-409
+    const bool pml = hasPml();
+    bool pmlDiag = true;
+    Cx tr[3][3], det(1.0, 0.0);
+    if (pml) {                                                                // :385-410 (mInvert = false: getS)
+      double pc[3];
+      compCoord(H_, comp0, cell, pc);
+      pmlDiag = pmlTransform(pc, false, tr, det);
+    }
+    if (muDiag && pmlDiag) {                                                  // :413-424
       const std::complex<double> fac = factor(B_, comp0, cell);
       rc[0] = (int32_t)r;
-      rv[0] = toScalar(fac * muHere);
+      Cx v = fac * muHere;
+      if (pml) v = cmul(v, cdiv(cmul(tr[comp0][comp0], tr[comp0][comp0]), det));
+      rv[0] = toScalar(v);
       cnt[r] = 1;
       continue;
     }
@@ -935,14 +1051,22 @@ Csr<S> YeeAssembler<S>::muOp() const {
       if (ok) use[nt++] = t;
     }
     double svals[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Cx svalsC[9];
     const double ntd = double(nt);
-    for (int u = 0; u < nt; ++u) {                                             // :424-437
+    for (int u = 0; u < nt; ++u) {                                             // :427-440
       const int* t = tupleInds[use[u]];
       int tcomps[3], tcells[3][3];
       for (int j = 0; j < 3; ++j) { tcomps[j] = scomps[t[j]]; for (int a = 0; a < 3; ++a) tcells[j][a] = scells[t[j]][a]; }
-      double m[3][3];
-      muTupleUpdate(tcomps, tcells, normal, m);
-      for (int j = 0; j < 3; ++j) svals[t[j]] += m[comp0][scomps[t[j]]] / ntd;
+      if (pml) {
+        Cx m[3][3];
+        muTupleUpdateC(tcomps, tcells, normal, m);
+        pmlSandwich(tr, det, m);                                              // :434
+        for (int j = 0; j < 3; ++j) svalsC[t[j]] = svalsC[t[j]] + m[comp0][scomps[t[j]]] / ntd;
+      } else {
+        double m[3][3];
+        muTupleUpdate(tcomps, tcells, normal, m);
+        for (int j = 0; j < 3; ++j) svals[t[j]] += m[comp0][scomps[t[j]]] / ntd;
+      }
     }
     int n = 0;
     for (int s = 0; s < 9; ++s) {                                              // :441-442
@@ -952,7 +1076,7 @@ Csr<S> YeeAssembler<S>::muOp() const {
       const int32_t lid = lidOf(B_, scomps[s], ic);
       if (lid < 0) continue;
       rc[n] = lid;
-      rv[n] = S(svals[s]) * toScalar(fac);
+      rv[n] = pml ? toScalar(cmul(svalsC[s], fac)) : S(svals[s]) * toScalar(fac);
       ++n;
     }
     for (int x = 1; x < n; ++x) {   // sort by column, merge repeated columns in insertion order (Epetra FillComplete)
@@ -999,6 +1123,14 @@ Csr<S> YeeAssembler<S>::invMuVolAve() const {
       out = out + fr * (3.0 / (m[0][0] + m[1][1] + m[2][2]));
     }
     out = out + (1.0 - sums) * (3.0 / 3.0);
+    if (hasPml()) {                                       // the layer's 'volume', :765-777: det of the getInvS product
+      double pc[3];
+      Cx tr[3][3], det;
+      compCoord(P_, 0, cell, pc);
+      pmlTransform(pc, true, tr, det);
+      d[r] = toScalar(cmul(Cx(out, 0.0), det));
+      continue;
+    }
     d[r] = S(out);
   }
   return diagonal<S>(d);
@@ -1024,7 +1156,15 @@ Csr<S> YeeAssembler<S>::invEpsVolAve() const {
         sums = sums + fr;
         acc = acc + cmul(std::complex<double>(fr, 0.0), cdiv(std::complex<double>(3.0, 0.0), tr));
       }
-      d[r] = toScalar(acc + std::complex<double>((1.0 - sums) * (3.0 / 3.0), 0.0));
+      acc = acc + std::complex<double>((1.0 - sums) * (3.0 / 3.0), 0.0);
+      if (hasPml()) {                                     // :779-791: det of the getS product
+        double pc[3];
+        Cx tr[3][3], det;
+        compCoord(P_, 0, cell, pc);
+        pmlTransform(pc, false, tr, det);
+        acc = cmul(acc, det);
+      }
+      d[r] = toScalar(acc);
       continue;
     }
     double out = 0.0, sums = 0.0;
@@ -1072,11 +1212,11 @@ std::map<std::string, Csr<S>> YeeAssembler<S>::singleOps() const {   // MxEMOps:
     o["dmL"] = fracs(E_, false);
     o["dmVInv"] = fracs(P_, true);
   }
-  if (hasDielectric()) {                                                   // src/MxEMOps.cpp:66-77
+  if (hasDielectric() || hasPml()) {                                       // src/MxEMOps.cpp:66-77
     o["invEps"] = invEps();
     o["invEpsVolAve"] = invEpsVolAve();
   }
-  if (hasMu()) {                                                           // src/MxEMOps.cpp:128-141
+  if (hasMu() || hasPml()) {                                               // src/MxEMOps.cpp:128-141
     o["mu"] = muOp();
     o["invMuVolAve"] = invMuVolAve();
   }

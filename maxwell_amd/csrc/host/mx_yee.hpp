@@ -53,6 +53,15 @@ struct YeeMu {
   double mu[3][3];
 };
 
+// <PML> block (src/MxProblem.cpp:559-598, src/MxPML.h): stretch s = 1 + i alphaMax ((x - begin) . dir / width)^exponent
+// along dir = (end - begin) / width inside `shape`; makes the problem complex
+struct YeePml {
+  std::string name;
+  std::shared_ptr<const Shape> shape;
+  double alphaMax = 1.0, exponent = 2.0;
+  double begin[3] = {0, 0, 0}, end[3] = {0, 0, 0};
+};
+
 struct YeeConfig {
   int n[3] = {16, 16, 16};
   double origin[3] = {0, 0, 0};
@@ -68,6 +77,7 @@ struct YeeConfig {
   double dmFrac = 0.0;   // <PEC> 'D-M frac' (src/MxProblem.cpp:450): B faces below it get factor 0
   std::vector<YeeDielectric> dielectrics;   // in deck order; background is vacuum (src/MxEMSim.cpp:32-33)
   std::vector<YeeMu> mus;                   // magnetic materials in deck order; background mu = 1
+  std::vector<YeePml> pmls;                 // perfectly matched layers in deck order
   // Distributed assembly (one GPU per MxGridDomain box, src/MxGrid.cpp:171-193): the cells this
   // rank owns, [boxLo, boxHi) per axis; boxHi[i] < 0 means the whole axis, [0, n+1).  The
   // assembler works on the box grown by `halo` cells wherever the axis is split, so the owned rows
@@ -102,6 +112,7 @@ class YeeAssembler {
   const YeeField& dfield() const { return D_; }
   bool hasDielectric() const { return !cfg_.dielectrics.empty(); }
   bool hasMu() const { return !cfg_.mus.empty(); }
+  bool hasPml() const { return !cfg_.pmls.empty(); }
   bool hasPec() const { return (bool)cfg_.pec; }
   const YeeConfig& config() const { return cfg_; }
   double cellSize(int i) const { return d_[i]; }
@@ -220,7 +231,13 @@ class YeeAssembler {
   void stencilNormal(int comp0, const int cell[3], const int scomps[9], const int scells[9][3], double n[3]) const;
   void tupleUpdate(const int comps[3], const int cells[3][3], const double n[3], double out[3][3]) const;
   void tupleUpdateC(const int comps[3], const int cells[3][3], const double n[3], std::complex<double> out[3][3]) const;
-  bool lossy_ = false;
+  void muTupleUpdateC(const int comps[3], const int cells[3][3], const double n[3], std::complex<double> out[3][3]) const;
+  // product of getInvS (inverse) / getS of the layers whose shape function is positive at p; returns "all diagonal"
+  bool pmlTransform(const double p[3], bool inverse, std::complex<double> t[3][3], std::complex<double>& det) const;
+  void compCoord(const YeeField& F, int comp, const int cell[3], double p[3]) const;
+  struct PmlGeom { double width, dir[3]; std::complex<double> outer[3][3], compl_[3][3]; };
+  std::vector<PmlGeom> pmlGeom_;
+  bool lossy_ = false;   // complex material arithmetic: a loss tangent or a PML
   void setMap(YeeField& F);
   struct Entry { int comp; int off[3]; double val; };
   Csr<S> assemble(const YeeField& rowF, const YeeField& colF, bool skipDeadRows,

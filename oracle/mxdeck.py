@@ -12,6 +12,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 from . import geometry as geo
+from . import yee
 from .yee import YeeSim
 
 SHAPE_TAGS = ("Ellipsoid", "Sphere", "Cylinder", "Torus", "Cone", "Slab", "HalfSpace", "ShapeSubtract",
@@ -151,6 +152,7 @@ class Deck:
         self.pec, self.dm_frac = None, 0.0
         self.dielectrics = []
         self.mus = []
+        self.pmls = []
         eig = None
         for child in root:
             if child.tag == "Grid":
@@ -185,6 +187,15 @@ class Deck:
                 mu[0, 2] = mu[2, 0] = off[1]
                 mu[1, 2] = mu[2, 1] = off[0]
                 self.mus.append((make_shape([c for c in child if c.tag in SHAPE_TAGS][0]), mu, name))
+            elif child.tag == "PML":                             # src/MxProblem.cpp:559-598
+                shp = [c for c in child if c.tag in SHAPE_TAGS]
+                if len(shp) != 1:
+                    raise ValueError("PML object needs to contain exactly 1 Shape object")
+                self.pmls.append(yee.Pml(make_shape(shp[0]), vec(get_attr("profile begin", child)), vec(get_attr("profile end", child)),
+                                         alpha_max=float(get_attr("max alpha", child, "1.0")),
+                                         exponent=float(get_attr("exponent", child, "2.0")),
+                                         name=get_attr("name", child, "PML%d" % len(self.pmls))))
+                self.params["is complex"] = True
             elif child.tag == "Eigensolver":
                 eig = child
         self._eigensolver(eig)
@@ -210,7 +221,7 @@ class Deck:
     def sim(self, strict=True):
         return YeeSim(self.n, origin=self.origin, size=self.size, lower=self.lower, upper=self.upper,
                       pec=self.pec, phase_shifts=self.phase, strict=strict, dm_frac=self.dm_frac,
-                      dielectrics=self.dielectrics, mus=self.mus)
+                      dielectrics=self.dielectrics, mus=self.mus, pmls=self.pmls)
 
 
 def load(path):

@@ -57,12 +57,48 @@ class _Field:
         self.cells = None
 
 
+class Pml:
+    """MxPML, src/MxPML.h:31-175: a stretched-coordinate layer whose stretch s = 1 + i alpha(x) does not depend on
+    frequency (alpha = alphaMax ((x - begin) . dir / width)^exponent), so the eigenproblem stays linear.  getInvS /
+    getS return dir dir^T s + (I - dir dir^T) and dir dir^T / s + (I - dir dir^T).  isDiag() is false for every
+    layer: setIsDiag counts |dir_i| < MxUtil::dEps, and dEps is 0.0 (src/MxUtil.hpp:26), so no component is ever
+    counted as zero - every row inside a layer takes the 9-point stencil path.  Complex arithmetic as in the rest of
+    this file: native (naive) products, the explicit naive quotient YeeSim._cdiv."""
+
+    def __init__(self, shape, begin, end, alpha_max=1.0, exponent=2.0, name="PML0"):
+        self.shape, self.name = shape, name
+        self.alpha_max, self.exponent = float(alpha_max), float(exponent)
+        self.start = [float(v) for v in begin]
+        self.end = [float(v) for v in end]
+        d = [self.end[i] - self.start[i] for i in range(3)]
+        import math
+        self.width = math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])          # :110-112
+        self.dir = [d[i] / self.width for i in range(3)]
+        dc = [complex(v, 0.0) for v in self.dir]
+        self.outer = [[dc[i] * dc[j] for j in range(3)] for i in range(3)]       # setOuterProds, :85-92
+        self.compl = [[complex(1.0 if i == j else 0.0, 0.0) - self.outer[i][j] for j in range(3)] for i in range(3)]
+        self.is_diag = False                                                      # setIsDiag with dEps = 0, :95-105
+
+    def alpha(self, point):                                                       # getAlpha, :168-171
+        t = ((point[0] - self.start[0]) * self.dir[0] + (point[1] - self.start[1]) * self.dir[1] +
+             (point[2] - self.start[2]) * self.dir[2]) / self.width
+        return self.alpha_max * float(np.float64(t) ** np.float64(self.exponent))
+
+    def inv_s(self, point):                                                       # getInvS, :145-149
+        s = complex(1.0, self.alpha(point))
+        return [[s * self.outer[i][j] + self.compl[i][j] for j in range(3)] for i in range(3)]
+
+    def s(self, point):                                                           # getS, :151-161 (m / s = m * (1 / s))
+        r = YeeSim._cdiv(complex(1.0, 0.0), complex(1.0, self.alpha(point)))
+        return [[r * self.outer[i][j] + self.compl[i][j] for j in range(3)] for i in range(3)]
+
+
 class YeeSim:
     """Single-rank 3-D restatement of MxEMSim::setup + MxEMOps + MxMagWaveOp::initMatrices."""
 
     def __init__(self, N, origin=(0., 0., 0.), size=(1., 1., 1.),
                  lower=("periodic",) * 3, upper=("periodic",) * 3,
-                 pec=None, phase_shifts=(0., 0., 0.), strict=True, dm_frac=0.0, dielectrics=(), mus=()):
+                 pec=None, phase_shifts=(0., 0., 0.), strict=True, dm_frac=0.0, dielectrics=(), mus=(), pmls=()):
         self.n = np.array([int(N)] * 3 if np.isscalar(N) else [int(x) for x in N])
         self.origin = np.array(origin, dtype=float)
         self.size = np.array(size, dtype=float)
@@ -87,17 +123,20 @@ class YeeSim:
             # a loss tangent makes eps complex (src/MxProblem.cpp:505-513): keep floats otherwise
             e = e.astype(complex) if np.iscomplexobj(e) and np.any(e.imag != 0.0) else e.real.astype(float)
             self.dielectrics.append((sh, e, name))
-        self.lossy = any(np.iscomplexobj(e) for _, e, _ in self.dielectrics)
+        # perfectly matched layers (Pml objects): complex materials; the D and H fields and both material operators are
+        # then built whether or not there is a dielectric / mu object (src/MxEMSim.cpp:89,96, src/MxEMOps.cpp:66,131)
+        self.pmls = list(pmls)
+        self.lossy = any(np.iscomplexobj(e) for _, e, _ in self.dielectrics) or bool(self.pmls)
         self.is_complex = self.is_complex or self.lossy
         # D lives where E lives (MxYeeElecFieldBase) but is represented by the dual face
         # (src/MxYeeFitDField.cpp:42-52); only built with dielectrics (src/MxEMSim.cpp:83-88)
-        D = _Field("dfield", 3, E.coords.copy(), [0, 1, 2]) if self.dielectrics else None
+        D = _Field("dfield", 3, E.coords.copy(), [0, 1, 2]) if (self.dielectrics or self.pmls) else None
         self.D = D
         # magnetic materials: (shape, 3x3 real symmetric mu, name), src/MxProblem.cpp:515-556 / MxMu.cpp.  H lives where B
         # lives (MxYeeMagFieldBase) but is represented by the dual edge through the face centre (src/MxYeeFitHField.cpp:37-47);
         # only built with mu objects (src/MxEMSim.cpp:95-100)
         self.mus = [(sh, np.array(mu, dtype=float).reshape(3, 3), name) for sh, mu, name in mus]
-        H = _Field("hfield", 3, B.coords.copy(), [0, 1, 2]) if self.mus else None
+        H = _Field("hfield", 3, B.coords.copy(), [0, 1, 2]) if (self.mus or self.pmls) else None
         self.H = H
         for F, normal_pec, tang_pec in ((B, ZERO, CONSTANT), (E, CONSTANT, ZERO)) + (((D, CONSTANT, ZERO),) if D else ()) + \
                 (((H, ZERO, CONSTANT),) if H else ()):
@@ -546,6 +585,31 @@ class YeeSim:
                 ave_p[j][k] += afj * pi[j][k]
         return geo._matmul3(ave_g, geo._inverse3(ave_p))
 
+    def _pml_transform(self, coord, inverse):
+        """Product of getInvS (inverse) / getS over the layers whose shape function is positive at `coord`
+        (src/MxYeeFitInvEps.cpp:514-537, src/MxYeeFitMu.cpp:385-410); returns (T, det T, all layers diagonal)."""
+        t = [[complex(1.0 if i == j else 0.0, 0.0) for j in range(3)] for i in range(3)]
+        diag = True
+        pt = np.array([[float(coord[0]), float(coord[1]), float(coord[2])]])
+        for pml in self.pmls:
+            if float(pml.shape.func(pt)[0]) > 0:
+                if not pml.is_diag:
+                    diag = False
+                t = self._matmul3c(t, pml.inv_s(coord) if inverse else pml.s(coord))
+        return t, self._det3c(t), diag
+
+    @staticmethod
+    def _det3c(m):
+        """det(MxDimMatrix<T, 3>), src/MxDimMatrix.hpp:376-384."""
+        return (m[0][0] * m[1][1] * m[2][2] + m[0][1] * m[1][2] * m[2][0] + m[0][2] * m[1][0] * m[2][1] -
+                m[0][2] * m[1][1] * m[2][0] - m[0][1] * m[1][0] * m[2][2] - m[0][0] * m[1][2] * m[2][1])
+
+    def _pml_sandwich(self, t, det, m):
+        """(T m T) / det with the matrix / scalar quotient as m * (1 / det) (src/MxDimMatrix.hpp:152-154)."""
+        r = self._matmul3c(self._matmul3c(t, m), t)
+        inv = self._cdiv(complex(1.0, 0.0), det)
+        return [[inv * r[i][j] for j in range(3)] for i in range(3)]
+
     def inv_eps(self):
         """MxYeeFitInvEps::setMatrix, src/MxYeeFitInvEps.cpp:421-560 (3-D, real eps, no PML): rows
         and columns on the E map; 1/eps_cc on rows wholly inside one (diagonal) material, otherwise
@@ -577,10 +641,16 @@ class YeeSim:
                     break
             if not in_diel:
                 eps_diag, eps_here = True, np.eye(3)
-            if eps_diag:                                                # :505-512
+            pml_diag = True
+            if self.pmls:                                               # :514-537
+                tr, det, pml_diag = self._pml_transform(self.comp_coord(E, comp0, cell), True)
+            if eps_diag and pml_diag:                                   # :542-549
                 fac = self.factor(D, comp0, cell[None, :])[0]
                 ecc = eps_here[comp0, comp0]
-                v = self._cdiv(fac, ecc) if self.lossy else complex(fac) / float(ecc.real)
+                if self.pmls:
+                    v = self._cdiv(self._cdiv(complex(fac) * tr[comp0][comp0] * tr[comp0][comp0], det), complex(ecc))
+                else:
+                    v = self._cdiv(fac, ecc) if self.lossy else complex(fac) / float(ecc.real)
                 rows.append(r); cols.append(r); vals.append(v)
                 continue
             comp1, comp2 = (comp0 + 1) % 3, (comp0 + 2) % 3            # getStencil, :35-71
@@ -607,6 +677,8 @@ class YeeSim:
             for t in tuples:                                            # :519-531
                 tc, tl = [scomps[si] for si in t], [scells[si] for si in t]
                 m = self._tuple_update_c(tc, tl, normal) if self.lossy else self._tuple_update(tc, tl, normal)
+                if self.pmls:                                           # :567
+                    m = self._pml_sandwich(tr, det, m)
                 for si in t:
                     svals[si] += m[comp0][scomps[si]] / nt
             for si in range(9):                                         # :533-537
@@ -681,6 +753,34 @@ class YeeSim:
                 ave_p[j][k] += afj * pi[j][k]
         return geo._matmul3(ave_p, geo._inverse3(ave_g))
 
+    def _mu_tuple_update_c(self, comps, cells, normal):
+        """_mu_tuple_update in complex arithmetic (the reference always computes it in MxComplex, :205-290)."""
+        ave_g = [[0j] * 3 for _ in range(3)]
+        ave_p = [[0j] * 3 for _ in range(3)]
+        lsum, asum = [0.0] * 3, [0.0] * 3
+        bg = [[1.0 if i == j else 0.0 for j in range(3)] for i in range(3)]
+        for sh, mu, name in self.mus:
+            lf, af = [0.0] * 3, [0.0] * 3
+            for j in range(3):
+                c = comps[j]
+                cell = np.array(cells[j])
+                lf[c] = float(self.frac_at(self.H, c, cell, name))
+                af[c] = float(self.frac_at(self.B, c, cell, name))
+                lsum[c] += lf[c]
+                asum[c] += af[c]
+            gamma, pi = self._gamma_pi_c(mu.tolist(), normal)
+            for j in range(3):
+                for k in range(3):
+                    ave_g[j][k] = ave_g[j][k] + complex(lf[j], 0.0) * gamma[j][k]
+                    ave_p[j][k] = ave_p[j][k] + complex(af[j], 0.0) * pi[j][k]
+        gamma, pi = self._gamma_pi_c(bg, normal)
+        for j in range(3):
+            lfj, afj = 1.0 - lsum[j], 1.0 - asum[j]
+            for k in range(3):
+                ave_g[j][k] = ave_g[j][k] + complex(lfj, 0.0) * gamma[j][k]
+                ave_p[j][k] = ave_p[j][k] + complex(afj, 0.0) * pi[j][k]
+        return self._matmul3c(ave_p, self._inverse3c(ave_g))
+
     def mu_op(self):
         """MxYeeFitMu::setMatrix with mInvert = false, src/MxYeeFitMu.cpp:294-463 (3-D, real mu, no PML): rows and
         columns on the B map; mu_cc on rows wholly inside one (diagonal) material, otherwise the 9-point stencil of
@@ -711,9 +811,15 @@ class YeeSim:
                     break
             if not in_mu:
                 mu_diag, mu_here = True, np.eye(3)
-            if mu_diag:                                                 # :398-409
+            pml_diag = True
+            if self.pmls:                                               # :385-410 (mInvert = false: getS)
+                tr, det, pml_diag = self._pml_transform(self.comp_coord(H, comp0, cell), False)
+            if mu_diag and pml_diag:                                    # :413-424
                 fac = self.factor(B, comp0, cell[None, :])[0]
-                rows.append(r); cols.append(r); vals.append(complex(fac) * float(mu_here[comp0, comp0]))
+                v = complex(fac) * float(mu_here[comp0, comp0])
+                if self.pmls:
+                    v = v * self._cdiv(tr[comp0][comp0] * tr[comp0][comp0], det)
+                rows.append(r); cols.append(r); vals.append(v)
                 continue
             comp1, comp2 = (comp0 + 1) % 3, (comp0 + 2) % 3            # getStencil, :27-71
             scomps = [comp0] + [comp1] * 4 + [comp2] * 4
@@ -736,9 +842,11 @@ class YeeSim:
                     tuples.append(t)
             svals = [0.0] * 9
             nt = float(len(tuples))
-            for t in tuples:                                            # :424-437
+            for t in tuples:                                            # :427-440
                 tc, tl = [scomps[si] for si in t], [scells[si] for si in t]
-                m = self._mu_tuple_update(tc, tl, normal)
+                m = self._mu_tuple_update_c(tc, tl, normal) if self.pmls else self._mu_tuple_update(tc, tl, normal)
+                if self.pmls:                                           # :434
+                    m = self._pml_sandwich(tr, det, m)
                 for si in t:
                     svals[si] += m[comp0][scomps[si]] / nt
             for si in range(9):                                         # :441-442
@@ -794,6 +902,9 @@ class YeeSim:
         out = out + (1.0 - sums) * (3.0 / 3.0)
         if self.is_complex:
             out = out.astype(complex)
+        if self.pmls:                                          # the layer's 'volume', :765-777: det of the getInvS product
+            for r in range(len(P.gids)):
+                out[r] = out[r] * self._pml_transform(self.comp_coord(P, 0, P.cells[r]), True)[1]
         return sp.diags(out, format="csr")
 
     def inv_eps_vol_ave(self):
@@ -822,6 +933,8 @@ class YeeSim:
                 sums = sums + f
                 acc = acc + complex(f, 0.0) * sc
             out[r] = acc + complex((1.0 - sums) * (3.0 / 3.0), 0.0)
+            if self.pmls:                                      # :779-791: det of the getS product
+                out[r] = out[r] * self._pml_transform(self.comp_coord(P, 0, P.cells[r]), False)[1]
         return sp.diags(out, format="csr")
 
     # ---------------------------------------------------------------- MxMagWaveOp matrices
@@ -833,10 +946,10 @@ class YeeSim:
             ops["dmA"] = self.fracs(self.B)
             ops["dmL"] = self.fracs(self.E)
             ops["dmVInv"] = self.fracs(self.P, inverse=True)
-        if self.dielectrics:                                   # src/MxEMOps.cpp:66-77
+        if self.dielectrics or self.pmls:                      # src/MxEMOps.cpp:66-77
             ops["invEps"] = self.inv_eps()
             ops["invEpsVolAve"] = self.inv_eps_vol_ave()
-        if self.mus:                                           # src/MxEMOps.cpp:128-141
+        if self.mus or self.pmls:                              # src/MxEMOps.cpp:128-141
             ops["mu"] = self.mu_op()
             ops["invMuVolAve"] = self.inv_mu_vol_ave()
         return ops

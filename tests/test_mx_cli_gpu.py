@@ -135,7 +135,7 @@ def test_maxwell_cli_errors(built, tmp_path):
     bad = tmp_path / "bad.mx"
     bad.write_text("<S>\n polarization = TE\n <PML>\n </PML>\n</S>\n")
     r = subprocess.run([CLI, "--infile=" + str(bad)], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and "<PML>" in r.stdout
+    assert r.returncode == 1 and "PML object" in r.stdout
 
 
 def test_transformed_cavity_deck_through_the_c_abi(ctx):
@@ -205,6 +205,32 @@ def test_magnetic_sphere_deck(ctx):
     # the empty cavity's lowest mode is k^2 = (2.7437 / 0.49)^2 = 31.4 (TM_11 of a PEC sphere): the magnetic
     # filling pulls it down, and the anisotropy splits the threefold degeneracy
     assert k2[0] < 0.6 * (2.743707269992265 / 0.49) ** 2 and k2[1] - k2[0] > 0.5 and k2[2] - k2[1] > 0.5
+
+
+def test_pml_decks_complex_frequencies(ctx):
+    """<PML> through MxProblem -> complex MxSolver (src/MxProblem.cpp:596-597 sets "is complex").
+    (a) a constant stretch over the whole box (tests/test_pml.py UNIFORM): the exact complex spectrum of the stretched
+    Yee grid; (b) tests/golden/pmlbox.mx, a layer at one end of a PEC box with a dielectric sphere, against the
+    oracle's dense restatement of the iterated operator: damped modes, Im k^2 < 0."""
+    from test_pml import UNIFORM, stretched_box_spectrum
+    text = UNIFORM.replace("DIR", "[1.0, 0.0, 0.0]")
+    deck = mxdeck.Deck(text)
+    prob = mx.Problem(text=text)
+    assert prob.is_complex
+    solver = prob.solver(ctx)
+    assert solver.solve() == 4
+    got = np.sort_complex(np.array([solver.result(i)["k2"] for i in range(4)]))
+    want = np.sort_complex(stretched_box_spectrum(deck.n, deck.size, [1.0 + 0.3j, 1.0, 1.0], 1.0, 4))
+    assert np.abs(got - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (got, want)
+
+    name = os.path.join(GOLDEN, "pmlbox.mx")
+    deck = mxdeck.load(name)
+    solver = mx.Problem(path=name).solver(ctx)
+    assert solver.solve() == 3
+    got = np.array(sorted((solver.result(i)["k2"] for i in range(3)), key=lambda z: z.real))
+    want = yee.mag_wave_modes(deck.sim().wave_ops(), deck.params["eigensolver : shift"], 3)
+    assert np.abs(got - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (got, want)
+    assert got[0].imag < -0.5 and got[1].imag < -0.5
 
 
 def test_complex_decks_bloch_phase_shifts(ctx):

@@ -15,7 +15,7 @@ from oracle import mxdeck
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 pytestmark = pytest.mark.usefixtures("built")
 DECKS = ["pillbox.mx", "pillbox_mxpy.mx", "vacuum.mx", "tilted_cavity.mx", "dsphmsph.mx", "crabcell.mx", "magsph.mx"]
-COMPLEX_DECKS = ["fiber.mx", "pillwtubes.mx"]
+COMPLEX_DECKS = ["fiber.mx", "pillwtubes.mx", "pmlbox.mx"]
 
 
 def _text(name):
@@ -80,7 +80,7 @@ def test_body_line_wins_over_tag_attribute():
     ("<S>\n polarization = TE\n <Dielectric>\n </Dielectric>\n</S>", "Dielectric"),
     ("<S>\n polarization = TE\n <Mu>\n </Mu>\n</S>", "Mu object"),
     ("<S>\n polarization = TE\n <Mu>\n loss tangent = 0.1\n <Sphere>\n name = a\n </Sphere>\n </Mu>\n</S>", "lossy <Mu>"),
-    ("<S>\n polarization = TE\n <PML>\n </PML>\n</S>", "<PML>"),
+    ("<S>\n polarization = TE\n <PML>\n </PML>\n</S>", "PML object"),
     ("<S>\n polarization = TE\n <PEC>\n <Torus>\n name = t\n </Torus>\n </PEC>\n</S>", "major radius"),
     ("<S>\n polarization = TE\n <PEC>\n <ShapeSubtract>\n <Sphere>\n name = a\n </Sphere>\n </ShapeSubtract>\n </PEC>\n</S>",
      "exactly 2"),
