@@ -40,6 +40,19 @@ class MultiVec {
   virtual void MvAddMv(Scalar alpha, const MultiVec<Scalar>& A, Scalar beta, const MultiVec<Scalar>& B) = 0;
   virtual void MvTransMv(Scalar alpha, const MultiVec<Scalar>& A,
                          Teuchos::SerialDenseMatrix<int, Scalar>& B) const = 0;
+  // B = alpha [A A2]^H this.  Not part of Anasazi's interface: the default is two MvTransMv calls; a multivector
+  // class that can do it in one pass over the rows overrides it (MxAnasaziMV -> mxg_mv_trans_mv2)
+  virtual void MvTransMv2(Scalar alpha, const MultiVec<Scalar>& A, const MultiVec<Scalar>& A2,
+                          Teuchos::SerialDenseMatrix<int, Scalar>& B) const {
+    const int m1 = A.GetNumberVecs(), m2 = A2.GetNumberVecs(), k = GetNumberVecs();
+    Teuchos::SerialDenseMatrix<int, Scalar> B1(m1, k), B2(m2, k);
+    MvTransMv(alpha, A, B1);
+    MvTransMv(alpha, A2, B2);
+    for (int j = 0; j < k; ++j) {
+      for (int i = 0; i < m1; ++i) B(i, j) = B1(i, j);
+      for (int i = 0; i < m2; ++i) B(m1 + i, j) = B2(i, j);
+    }
+  }
   virtual void MvDot(const MultiVec<Scalar>& A, std::vector<Scalar>& b) const = 0;
   virtual void MvNorm(std::vector<typename ScalarTraits<Scalar>::magnitudeType>& normvec) const = 0;
   virtual void SetBlock(const MultiVec<Scalar>& A, const std::vector<int>& index) = 0;
@@ -374,16 +387,12 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
           op->Apply(*Vact, *W);
         }
         ++iters_;
+        // H = V^H (M) W together with the size of Op*v before orthogonalisation (the breakdown reference), one pass:
+        // [V W]^H (M) W; then W -= V H  (classical Gram-Schmidt, twice)
         std::vector<double> scale(b);
-        for (int j = 0; j < b; ++j) {     // size of Op*v before orthogonalisation: breakdown reference
-          std::unique_ptr<MV> wj(W->CloneViewNonConst(range(j, 1)));
-          std::unique_ptr<MV> mwj(MW ? MW->CloneViewNonConst(range(0, 1)) : nullptr);
-          scale[j] = mnorm(*wj, mwj.get(), M);
-        }
-        // H = V^H (M) W, W -= V H  (classical Gram-Schmidt, twice)
         Dense h(k, b), h2(k, b);
         std::unique_ptr<const MV> Vk(V->CloneView(range(0, k)));
-        innerProd(*Vk, *W, MW.get(), M, h);
+        innerProdNorms(*Vk, *W, MW.get(), M, h, scale);
         W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h, ScalarTraits<Scalar>::one());
         innerProd(*Vk, *W, MW.get(), M, h2);
         W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h2, ScalarTraits<Scalar>::one());
@@ -501,15 +510,12 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
           op->Apply(*Vact, *W);
         }
         ++iters_;
+        // H = V^H (M) W together with the size of Op*v before orthogonalisation (the breakdown reference), one pass:
+        // [V W]^H (M) W; then W -= V H  (classical Gram-Schmidt, twice)
         std::vector<double> scale(b);
-        for (int j = 0; j < b; ++j) {
-          std::unique_ptr<MV> wj(W->CloneViewNonConst(range(j, 1)));
-          std::unique_ptr<MV> mwj(MW ? MW->CloneViewNonConst(range(0, 1)) : nullptr);
-          scale[j] = mnorm(*wj, mwj.get(), M);
-        }
         Dense h(k, b), h2(k, b);
         std::unique_ptr<const MV> Vk(V->CloneView(range(0, k)));
-        innerProd(*Vk, *W, MW.get(), M, h);
+        innerProdNorms(*Vk, *W, MW.get(), M, h, scale);
         W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h, ScalarTraits<Scalar>::one());
         innerProd(*Vk, *W, MW.get(), M, h2);
         W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h2, ScalarTraits<Scalar>::one());
@@ -710,15 +716,12 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
           op->Apply(*Vact, *W);
         }
         ++iters_;
+        // H = V^H (M) W together with the size of Op*v before orthogonalisation (the breakdown reference), one pass:
+        // [V W]^H (M) W; then W -= V H  (classical Gram-Schmidt, twice)
         std::vector<double> scale(b);
-        for (int j = 0; j < b; ++j) {
-          std::unique_ptr<MV> wj(W->CloneViewNonConst(range(j, 1)));
-          std::unique_ptr<MV> mwj(MW ? MW->CloneViewNonConst(range(0, 1)) : nullptr);
-          scale[j] = mnorm(*wj, mwj.get(), M);
-        }
         Dense h(k, b), h2(k, b);
         std::unique_ptr<const MV> Vk(V->CloneView(range(0, k)));
-        innerProd(*Vk, *W, MW.get(), M, h);
+        innerProdNorms(*Vk, *W, MW.get(), M, h, scale);
         W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h, ScalarTraits<Scalar>::one());
         innerProd(*Vk, *W, MW.get(), M, h2);
         W->MvTimesMatAddMv(-ScalarTraits<Scalar>::one(), *Vk, h2, ScalarTraits<Scalar>::one());
@@ -903,6 +906,19 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
       wj->MvScale(Scalar(1.0 / nrm));
     }
     return rank;
+  }
+
+  // C = A^H (M) B and norms[j] = sqrt(B_j^H (M) B_j) from one pass over the rows: [A B]^H (M B)
+  static void innerProdNorms(const MV& A, const MV& B, MV* MB, const RCP<OP>& M, Dense& C, std::vector<double>& norms) {
+    const int k = A.GetNumberVecs(), b = B.GetNumberVecs();
+    Dense ext(k + b, b);
+    if (M.is_null()) B.MvTransMv2(ScalarTraits<Scalar>::one(), A, B, ext);
+    else { M->Apply(B, *MB); MB->MvTransMv2(ScalarTraits<Scalar>::one(), A, B, ext); }
+    for (int j = 0; j < b; ++j) {
+      for (int i = 0; i < k; ++i) C(i, j) = ext(i, j);
+      const double v = ScalarTraits<Scalar>::real(ext(k + j, j));
+      norms[j] = v > 0 ? std::sqrt(v) : 0.0;
+    }
   }
 
   static double mnorm(const MV& w, MV* mw, const RCP<OP>& M) {

@@ -61,6 +61,19 @@ class MxAnasaziMV : public Anasazi::MultiVec<Scalar>, public MxMultiVector<Scala
     MX_ABI(mxg_mv_trans_mv(mxRe(alpha), mxIm(alpha), Av->raw(), this->raw(), reinterpret_cast<double*>(B.values()),
                            B.stride()), "MxAnasaziMV::MvTransMv");
   }
+  // B = alpha * [A A2]^H * this, one pass over the rows (mxg_mv_trans_mv2)
+  virtual void MvTransMv2(Scalar alpha, const Anasazi::MultiVec<Scalar>& A, const Anasazi::MultiVec<Scalar>& A2,
+                          Teuchos::SerialDenseMatrix<int, Scalar>& B) const {
+    const MxAnasaziMV<Scalar>* Av = dynamic_cast<const MxAnasaziMV<Scalar>*>(&A);
+    const MxAnasaziMV<Scalar>* A2v = dynamic_cast<const MxAnasaziMV<Scalar>*>(&A2);
+    if (Av == NULL || A2v == NULL) { std::cout << "MxAnasaziMV::MvTransMv2 cast failed\n"; exit(EXIT_FAILURE); }
+    if (B.numRows() != Av->GetNumberVecs() + A2v->GetNumberVecs() || B.numCols() != GetNumberVecs()) {
+      std::cout << "MxAnasaziMV::MvTransMv2: B is " << B.numRows() << "x" << B.numCols() << "\n";
+      exit(EXIT_FAILURE);
+    }
+    MX_ABI(mxg_mv_trans_mv2(mxRe(alpha), mxIm(alpha), Av->raw(), A2v->raw(), this->raw(), reinterpret_cast<double*>(B.values()),
+                            B.stride()), "MxAnasaziMV::MvTransMv2");
+  }
   virtual void MvDot(const Anasazi::MultiVec<Scalar>& A, std::vector<Scalar>& b) const {
     this->dot(dynamic_cast<const MxAnasaziMV<Scalar>&>(A), b);
   }

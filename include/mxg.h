@@ -180,6 +180,11 @@ int mxg_mv_times_mat(double alpha_re, double alpha_im, const mxg_mv* A, const do
  * all-reduced */
 int mxg_mv_trans_mv(double alpha_re, double alpha_im, const mxg_mv* A, const mxg_mv* self,
                     double* B, int ldb);
+/* B((m + m2) x k) = alpha * [A A2]^H * this in ONE pass over the rows (A2 may be NULL).  The block Krylov-Schur step
+ * of Anasazi (called from src/MxSolver.cpp:100-104) needs V^H w (MvTransMv) and w^H w (MvNorm / MvDot) of the same
+ * w back to back; with A2 = w both come from one launch.  All-reduced. */
+int mxg_mv_trans_mv2(double alpha_re, double alpha_im, const mxg_mv* A, const mxg_mv* A2, const mxg_mv* self,
+                     double* B, int ldb);
 
 /* ------------------------------------------------------------------------------------------
  * inner Krylov solves  (replaces AztecOO::recursiveIterate + TrueResidual loop,

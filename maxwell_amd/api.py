@@ -246,11 +246,13 @@ class MultiVec:
         _chk(self.lib.mxg_mv_times_mat(alpha.real, alpha.imag, A.h, _ptr(B), m, m, k,
                                        beta.real, beta.imag, self.h), self.lib)
 
-    def trans_mv(self, alpha, A):   # B = alpha * A^H * this
+    def trans_mv(self, alpha, A, A2=None):   # B = alpha * [A A2]^H * this (one pass over the rows)
         dt = np.complex128 if self.is_complex else np.float64
-        B = np.empty((A.k, self.k), dtype=dt, order="F")
+        m = A.k + (A2.k if A2 is not None else 0)
+        B = np.empty((m, self.k), dtype=dt, order="F")
         alpha = complex(alpha)
-        _chk(self.lib.mxg_mv_trans_mv(alpha.real, alpha.imag, A.h, self.h, _ptr(B), A.k), self.lib)
+        _chk(self.lib.mxg_mv_trans_mv2(alpha.real, alpha.imag, A.h, A2.h if A2 is not None else None, self.h, _ptr(B), m),
+             self.lib)
         return B
 
     def close(self):

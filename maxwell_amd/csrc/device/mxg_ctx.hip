@@ -144,6 +144,8 @@ int mxg_ctx_reserve_reduce(mxg_ctx* c, size_t width) {
   MXG_HIP(hipMalloc(&c->d_partial, sizeof(double) * w * MXG_MAX_RED_BLOCKS));
   MXG_HIP(hipMalloc(&c->d_result, sizeof(double) * w));
   MXG_HIP(hipHostMalloc(&c->h_result, sizeof(double) * w, hipHostMallocDefault));
+  void* dev = nullptr;
+  c->h_result_dev = hipHostGetDevicePointer(&dev, c->h_result, 0) == hipSuccess ? (double*)dev : nullptr;
   c->red_width = w;
   return 0;
 }

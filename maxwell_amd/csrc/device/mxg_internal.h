@@ -67,6 +67,7 @@ struct mxg_ctx {
   double* d_partial = nullptr;   // MXG_MAX_RED_BLOCKS * red_width doubles
   double* d_result = nullptr;    // red_width doubles
   double* h_result = nullptr;    // pinned, red_width doubles
+  double* h_result_dev = nullptr;   // the same buffer as the device sees it (kernels store results straight into it)
   size_t red_width = 0;          // capacity (number of simultaneous scalar results)
   // small dense operand staging (B of K6) and int index staging
   double* d_small = nullptr;

@@ -146,9 +146,13 @@ int launch_ew(mxg_ctx* c, const EwArgs& g) {
 }
 
 // ---------------------------------------------------------------- dot products (K2/K3)
-// partial[(2j+c) * MAXB + blockIdx.x]; c = 0 real part, 1 imaginary part (complex only)
-template <bool CPLX>
-__global__ void k_dot(MvDesc A, MvDesc B, double* __restrict__ partial) {
+// partial[(2j+c) * MAXB + blockIdx.x]; c = 0 real part, 1 imaginary part (complex only).  Four 16-byte loads per
+// operand in flight per thread.  SELF: norm2, the operand is read once.  The second stage (k_reduce_final) adds the
+// partials in block order and stores the result - straight into the pinned host buffer when the caller wants it there.
+// (A fused "last block adds the partials" variant was measured and dropped: the device-scope fence each block needs
+// before it signals writes back / invalidates the XCD's L2 and doubled the kernel time, profiles/r02c.)
+template <bool CPLX, bool SELF>
+__global__ void __launch_bounds__(BLK) k_dot(MvDesc A, MvDesc B, double* __restrict__ partial) {
   __shared__ double lds[BLK / 64];
   const int j = blockIdx.y;
   const double* a = A.col(j);
@@ -159,14 +163,30 @@ __global__ void k_dot(MvDesc A, MvDesc B, double* __restrict__ partial) {
   const double2* b2 = reinterpret_cast<const double2*>(b);
   double sr = 0.0, si = 0.0;
   const long long stride = (long long)gridDim.x * BLK;
-  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < npair; i += stride) {
-    double2 va = a2[i], vb = b2[i];
-    sr += va.x * vb.x + va.y * vb.y;
-    if (CPLX) si += va.x * vb.y - va.y * vb.x;
+  long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  constexpr int U = 4;
+  for (; i + (U - 1) * stride < npair; i += U * stride) {
+    double2 va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      va[u] = a2[i + u * stride];
+      if (!SELF) vb[u] = b2[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double2 x = va[u], y = SELF ? va[u] : vb[u];
+      sr += x.x * y.x + x.y * y.y;
+      if (CPLX && !SELF) si += x.x * y.y - x.y * y.x;
+    }
+  }
+  for (; i < npair; i += stride) {
+    const double2 x = a2[i], y = SELF ? x : b2[i];
+    sr += x.x * y.x + x.y * y.y;
+    if (CPLX && !SELF) si += x.x * y.y - x.y * y.x;
   }
   if (!CPLX && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) sr += a[n - 1] * b[n - 1];
-  double r = block_sum(sr, lds);
   const int width = CPLX ? 2 : 1;
+  double r = block_sum(sr, lds);
   if (threadIdx.x == 0) partial[(size_t)(width * j) * MXG_MAX_RED_BLOCKS + blockIdx.x] = r;
   if (CPLX) {
     double q = block_sum(si, lds);
@@ -174,88 +194,100 @@ __global__ void k_dot(MvDesc A, MvDesc B, double* __restrict__ partial) {
   }
 }
 
-// ---------------------------------------------------------------- B = A^H T (K7)
-// Thread-private accumulation of an LT x KT tile of B over a grid-stride loop of rows, one
-// block reduction at the end.  partial[((l0+l) + m*(j0+j)) * width + c] per block.
+// ---------------------------------------------------------------- B = [A A2]^H T (K7)
+// One pass over the rows for every m: all four wavefronts of a block walk the same rows, wavefront w owns the LT
+// columns of [A A2] of tile w (then w + 4, ...) and all KT columns of T - the columns of T are fetched from HBM once
+// per 4 LT columns and served to the other three wavefronts by the caches, every column of A exactly once.  Thread-
+// private LT x KT accumulators over a grid-stride loop, one wavefront shuffle reduction per accumulator at the end
+// (no block-level step: the wavefronts own different entries).  A2 (m2 columns, may be 0) is appended after A: the
+// Krylov-Schur step gets V^H w and w^H w from one launch.  partial[((l) + m*(j0+j)) * width + c] per block.
 template <int LT, int KT, bool CPLX>
-__global__ void k_trans_mv(MvDesc A, MvDesc T, int l0, int j0, int m, double* __restrict__ partial) {
-  __shared__ double lds[BLK / 64];
-  const long long n = A.n;
-  const double* ap[LT];
+__global__ void __launch_bounds__(BLK) k_trans_mv(MvDesc A, MvDesc A2, MvDesc T, int j0, int m, double* __restrict__ partial) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long n = T.n;
+  const int m1 = A.k;
   const double* tp[KT];
 #pragma unroll
-  for (int l = 0; l < LT; ++l) ap[l] = A.col(min(l0 + l, A.k - 1));
-#pragma unroll
   for (int j = 0; j < KT; ++j) tp[j] = T.col(min(j0 + j, T.k - 1));
-  double acc[LT][KT][CPLX ? 2 : 1];
+  const long long stride = (long long)gridDim.x * 64;
+  const int width = CPLX ? 2 : 1;
+  const long long nelem = CPLX ? n : n / 2;
+  for (int l0 = wave * LT; l0 < m; l0 += (BLK / 64) * LT) {
+    const double* ap[LT];
 #pragma unroll
-  for (int l = 0; l < LT; ++l)
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      acc[l][j][0] = 0.0;
-      if (CPLX) acc[l][j][1] = 0.0;
+    for (int l = 0; l < LT; ++l) {
+      const int ll = min(l0 + l, m - 1);
+      ap[l] = ll < m1 ? A.col(ll) : A2.col(ll - m1);
     }
-  const long long stride = (long long)gridDim.x * BLK;
-  if constexpr (CPLX) {
-  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
-    {
-      double2 tv[KT];
+    double acc[LT][KT][CPLX ? 2 : 1];
+#pragma unroll
+    for (int l = 0; l < LT; ++l)
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        acc[l][j][0] = 0.0;
+        if (CPLX) acc[l][j][1] = 0.0;
+      }
+    for (long long i = (long long)blockIdx.x * 64 + lane; i < nelem; i += stride) {
+      double2 tv[KT], av[LT];
 #pragma unroll
       for (int j = 0; j < KT; ++j) tv[j] = reinterpret_cast<const double2*>(tp[j])[i];
 #pragma unroll
-      for (int l = 0; l < LT; ++l) {
-        double2 av = reinterpret_cast<const double2*>(ap[l])[i];
+      for (int l = 0; l < LT; ++l) av[l] = reinterpret_cast<const double2*>(ap[l])[i];
+#pragma unroll
+      for (int l = 0; l < LT; ++l)
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
-          acc[l][j][0] += av.x * tv[j].x + av.y * tv[j].y;
-          acc[l][j][1] += av.x * tv[j].y - av.y * tv[j].x;
+          if (CPLX) {
+            acc[l][j][0] += av[l].x * tv[j].x + av[l].y * tv[j].y;
+            acc[l][j][1] += av[l].x * tv[j].y - av[l].y * tv[j].x;
+          } else {
+            acc[l][j][0] += av[l].x * tv[j].x + av[l].y * tv[j].y;
+          }
         }
-      }
     }
-  }
-  }
-  if constexpr (!CPLX) {
-    // real: two rows per thread and iteration through 16-byte loads
-    const long long npair = n / 2;
-    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < npair; i += stride) {
-      double2 tv[KT];
-#pragma unroll
-      for (int j = 0; j < KT; ++j) tv[j] = reinterpret_cast<const double2*>(tp[j])[i];
-#pragma unroll
-      for (int l = 0; l < LT; ++l) {
-        const double2 av = reinterpret_cast<const double2*>(ap[l])[i];
-#pragma unroll
-        for (int j = 0; j < KT; ++j) acc[l][j][0] += av.x * tv[j].x + av.y * tv[j].y;
-      }
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!CPLX && (n & 1) && blockIdx.x == 0 && lane == 0) {
 #pragma unroll
       for (int l = 0; l < LT; ++l)
 #pragma unroll
         for (int j = 0; j < KT; ++j) acc[l][j][0] += ap[l][n - 1] * tp[j][n - 1];
     }
-  }
-  const int width = CPLX ? 2 : 1;
 #pragma unroll
-  for (int l = 0; l < LT; ++l)
+    for (int l = 0; l < LT; ++l)
 #pragma unroll
-    for (int j = 0; j < KT; ++j)
+      for (int j = 0; j < KT; ++j)
 #pragma unroll
-      for (int c = 0; c < width; ++c) {
-        double r = block_sum(acc[l][j][c], lds);
-        if (threadIdx.x == 0 && l0 + l < A.k && j0 + j < T.k) {
-          size_t slot = ((size_t)(l0 + l) + (size_t)m * (j0 + j)) * width + c;
-          partial[slot * MXG_MAX_RED_BLOCKS + blockIdx.x] = r;
+        for (int c = 0; c < width; ++c) {
+          const double r = wave_sum(acc[l][j][c]);
+          if (lane == 0 && l0 + l < m && j0 + j < T.k) {
+            const size_t slot = ((size_t)(l0 + l) + (size_t)m * (j0 + j)) * width + c;
+            partial[slot * MXG_MAX_RED_BLOCKS + blockIdx.x] = r;
+          }
         }
-      }
+  }
 }
 
 // ---------------------------------------------------------------- Y = alpha A B + beta Y (K6)
-// One thread per row, KT accumulators, B (already scaled by alpha) read through uniform loads.
-template <int KT, bool CPLX>
-__global__ void k_times_mat(MvDesc A, const double* __restrict__ Bs, int m, int j0, int kcols,
-                            double br, double bi, MvDesc Y) {
-  // one element = one complex number, or two consecutive real rows (16-byte accesses either way)
+// One thread per element (a complex number, or two consecutive real rows: 16-byte accesses either way), KT
+// accumulators, a single pass over A and Y for every m.  The m x KT coefficients (already scaled by alpha) sit in
+// LDS, zero-padded to a multiple of UL rows, and are read as broadcasts; UL columns of A are loaded before their
+// FMAs so that UL 16-byte loads per thread are in flight (the loop over m used to issue one load at a time).
+constexpr int TM_UL = 6;
+constexpr int TM_LDS_DOUBLES = 6144;   // m * KT * (1 or 2) coefficients; larger products read them from global memory
+
+template <int KT, bool CPLX, bool INLDS>
+__global__ void __launch_bounds__(BLK) k_times_mat(MvDesc A, const double* __restrict__ Bs, int m, int j0, int kcols,
+                                                    double br, double bi, MvDesc Y) {
+  constexpr int W = CPLX ? 2 : 1;
+  __shared__ double sB[INLDS ? TM_LDS_DOUBLES : 1];
+  const int mpad = (m + TM_UL - 1) / TM_UL * TM_UL;
+  if (INLDS) {
+    for (int q = threadIdx.x; q < mpad * KT * W; q += BLK) {
+      const int c = q % W, j = (q / W) % KT, l = q / (W * KT);
+      const int jj = min(j0 + j, kcols - 1);
+      sB[q] = l < m ? Bs[((size_t)l + (size_t)m * jj) * W + c] : 0.0;
+    }
+    __syncthreads();
+  }
   const long long n = Y.n;
   const long long nelem = CPLX ? n : n / 2;
   const long long stride = (long long)gridDim.x * BLK;
@@ -263,20 +295,32 @@ __global__ void k_times_mat(MvDesc A, const double* __restrict__ Bs, int m, int 
     double2 acc[KT];
 #pragma unroll
     for (int j = 0; j < KT; ++j) acc[j] = make_double2(0.0, 0.0);
-    for (int l = 0; l < m; ++l) {
-      const double2 av = reinterpret_cast<const double2*>(A.col(l))[i];
+    for (int l0 = 0; l0 < m; l0 += TM_UL) {
+      double2 av[TM_UL];
 #pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        const int jj = min(j0 + j, kcols - 1);
-        if (CPLX) {
-          const double bre = Bs[((size_t)l + (size_t)m * jj) * 2];
-          const double bim = Bs[((size_t)l + (size_t)m * jj) * 2 + 1];
-          acc[j].x += av.x * bre - av.y * bim;
-          acc[j].y += av.x * bim + av.y * bre;
-        } else {
-          const double b = Bs[(size_t)l + (size_t)m * jj];
-          acc[j].x += av.x * b;
-          acc[j].y += av.y * b;
+      for (int u = 0; u < TM_UL; ++u) av[u] = reinterpret_cast<const double2*>(A.col(min(l0 + u, m - 1)))[i];
+#pragma unroll
+      for (int u = 0; u < TM_UL; ++u) {
+        const int l = l0 + u;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          double bre, bim = 0.0;
+          if (INLDS) {
+            bre = sB[(l * KT + j) * W];
+            if (CPLX) bim = sB[(l * KT + j) * W + 1];
+          } else {
+            const int jj = min(j0 + j, kcols - 1);
+            const bool in = l < m;
+            bre = in ? Bs[((size_t)l + (size_t)m * jj) * W] : 0.0;
+            if (CPLX) bim = in ? Bs[((size_t)l + (size_t)m * jj) * W + 1] : 0.0;
+          }
+          if (CPLX) {
+            acc[j].x += av[u].x * bre - av[u].y * bim;
+            acc[j].y += av[u].x * bim + av[u].y * bre;
+          } else {
+            acc[j].x += av[u].x * bre;
+            acc[j].y += av[u].y * bre;
+          }
         }
       }
     }
@@ -521,31 +565,45 @@ int mxg_dev_dot(mxg_ctx* c, const MvDesc& A, const MvDesc& B, double* d_out) {
   const long long npair = A.cplx ? A.n : (A.n + 1) / 2;
   const int gx = mxg_grid_for(npair, BLK, 8, 1024);
   dim3 grid(gx, A.k);
-  if (A.cplx) hipLaunchKernelGGL((k_dot<true>), grid, dim3(BLK), 0, c->stream, A, B, c->d_partial);
-  else hipLaunchKernelGGL((k_dot<false>), grid, dim3(BLK), 0, c->stream, A, B, c->d_partial);
-  hipLaunchKernelGGL(k_reduce_final, dim3(A.k * width), dim3(BLK), 0, c->stream, c->d_partial, gx,
-                     d_out);
+  const bool self = A.base == B.base && A.ld == B.ld && A.col0 == B.col0 && A.cols == B.cols;
+  if (A.cplx) {
+    if (self) hipLaunchKernelGGL((k_dot<true, true>), grid, dim3(BLK), 0, c->stream, A, B, c->d_partial);
+    else hipLaunchKernelGGL((k_dot<true, false>), grid, dim3(BLK), 0, c->stream, A, B, c->d_partial);
+  } else {
+    if (self) hipLaunchKernelGGL((k_dot<false, true>), grid, dim3(BLK), 0, c->stream, A, B, c->d_partial);
+    else hipLaunchKernelGGL((k_dot<false, false>), grid, dim3(BLK), 0, c->stream, A, B, c->d_partial);
+  }
+  hipLaunchKernelGGL(k_reduce_final, dim3(A.k * width), dim3(BLK), 0, c->stream, c->d_partial, gx, d_out);
   MXG_HIP(hipGetLastError());
+  return 0;
+}
+
+// dot / norm to the host: without a communicator the second stage stores straight into the pinned result buffer (no
+// copy call: two launches + one stream wait per call); with one, the device buffer is all-reduced first
+static int dot_to_host(mxg_ctx* c, const MvDesc& A, const MvDesc& B, size_t w, double* host_out) {
+  MXG_TRY(mxg_ctx_reserve_reduce(c, w));
+  static const bool hostout = !(getenv("MXG_DOT_HOSTOUT") && atoi(getenv("MXG_DOT_HOSTOUT")) == 0);
+  if (mxg_comm_on(c) || !c->h_result_dev || !hostout) {
+    MXG_TRY(mxg_dev_dot(c, A, B, c->d_result));
+    return mxg_ctx_finish_reduce(c, w, host_out);
+  }
+  MXG_TRY(mxg_dev_dot(c, A, B, c->h_result_dev));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  memcpy(host_out, c->h_result, sizeof(double) * w);
   return 0;
 }
 
 extern "C" int mxg_mv_dot(const mxg_mv* A, const mxg_mv* B, double* res) {
   MXG_CHECK(same_shape(A, B), "mxg_mv_dot: shape mismatch");
-  mxg_ctx* c = A->ctx;
   const size_t w = (size_t)A->k * (A->is_complex ? 2 : 1);
-  MXG_TRY(mxg_ctx_reserve_reduce(c, w));
-  MXG_TRY(mxg_dev_dot(c, A->desc(), B->desc(), c->d_result));
-  return mxg_ctx_finish_reduce(c, w, res);
+  return dot_to_host(A->ctx, A->desc(), B->desc(), w, res);
 }
 
 extern "C" int mxg_mv_norm2(const mxg_mv* v, double* res) {
-  mxg_ctx* c = v->ctx;
   const int width = v->is_complex ? 2 : 1;
   const size_t w = (size_t)v->k * width;
-  MXG_TRY(mxg_ctx_reserve_reduce(c, w));
-  MXG_TRY(mxg_dev_dot(c, v->desc(), v->desc(), c->d_result));
   std::vector<double> tmp(w);
-  MXG_TRY(mxg_ctx_finish_reduce(c, w, tmp.data()));
+  MXG_TRY(dot_to_host(v->ctx, v->desc(), v->desc(), w, tmp.data()));
   for (int j = 0; j < v->k; ++j) res[j] = sqrt(tmp[(size_t)j * width]);
   return 0;
 }
@@ -574,8 +632,11 @@ namespace {
 template <int KT, bool CPLX>
 void launch_times_mat(mxg_ctx* c, int grid, const MvDesc& A, const double* Bs, int m, int j0,
                       int kcols, double br, double bi, const MvDesc& Y) {
-  hipLaunchKernelGGL((k_times_mat<KT, CPLX>), dim3(grid), dim3(BLK), 0, c->stream, A, Bs, m, j0,
-                     kcols, br, bi, Y);
+  const int mpad = (m + TM_UL - 1) / TM_UL * TM_UL;
+  if ((size_t)mpad * KT * (CPLX ? 2 : 1) <= (size_t)TM_LDS_DOUBLES)
+    hipLaunchKernelGGL((k_times_mat<KT, CPLX, true>), dim3(grid), dim3(BLK), 0, c->stream, A, Bs, m, j0, kcols, br, bi, Y);
+  else
+    hipLaunchKernelGGL((k_times_mat<KT, CPLX, false>), dim3(grid), dim3(BLK), 0, c->stream, A, Bs, m, j0, kcols, br, bi, Y);
 }
 template <bool CPLX>
 void dispatch_times_mat(mxg_ctx* c, int grid, const MvDesc& A, const double* Bs, int m, int kcols,
@@ -627,36 +688,59 @@ extern "C" int mxg_mv_times_mat(double alr, double ali, const mxg_mv* A, const d
 
 namespace {
 template <int LT, int KT, bool CPLX>
-void launch_trans_mv(mxg_ctx* c, int gx, const MvDesc& A, const MvDesc& T, int m, int k) {
+void launch_trans_mv(mxg_ctx* c, int gx, const MvDesc& A, const MvDesc& A2, const MvDesc& T, int m, int k) {
   for (int j0 = 0; j0 < k; j0 += KT)
-    for (int l0 = 0; l0 < m; l0 += LT)
-      hipLaunchKernelGGL((k_trans_mv<LT, KT, CPLX>), dim3(gx), dim3(BLK), 0, c->stream, A, T, l0, j0,
-                         m, c->d_partial);
+    hipLaunchKernelGGL((k_trans_mv<LT, KT, CPLX>), dim3(gx), dim3(BLK), 0, c->stream, A, A2, T, j0, m, c->d_partial);
 }
 }  // namespace
 
-extern "C" int mxg_mv_trans_mv(double alr, double ali, const mxg_mv* A, const mxg_mv* self,
-                               double* B, int ldb) {
+// B = alpha [A A2]^H self, (A.k + A2.k) x self.k; A2 may be NULL
+extern "C" int mxg_mv_trans_mv2(double alr, double ali, const mxg_mv* A, const mxg_mv* A2, const mxg_mv* self,
+                                double* B, int ldb) {
   MXG_CHECK(A->nlocal == self->nlocal && A->is_complex == self->is_complex,
             "mxg_mv_trans_mv: shape mismatch");
+  MXG_CHECK(!A2 || (A2->nlocal == self->nlocal && A2->is_complex == self->is_complex && A2->ctx == self->ctx),
+            "mxg_mv_trans_mv2: shape mismatch of the appended columns");
   mxg_ctx* c = self->ctx;
-  const int m = A->k, k = self->k;
+  const int m = A->k + (A2 ? A2->k : 0), k = self->k;
   MXG_CHECK(ldb >= m, "mxg_mv_trans_mv: ldb %d < m %d", ldb, m);
   const bool cplx = self->is_complex;
   const int w = cplx ? 2 : 1;
   const size_t width = (size_t)m * k * w;
   MXG_TRY(mxg_ctx_reserve_reduce(c, width));
-  const int gx = mxg_grid_for(self->is_complex ? self->nlocal : (self->nlocal + 1) / 2, BLK, 4, 1024);
-  MvDesc Ad = A->desc(), Td = self->desc();
+  // each block walks 64 elements per step (the four wavefronts share the rows)
+  const int gx = mxg_grid_for(self->is_complex ? self->nlocal : (self->nlocal + 1) / 2, 64, 8, 1024);
+  MvDesc Ad = A->desc(), A2d = A2 ? A2->desc() : A->desc(), Td = self->desc();
+  // single vectors (the Krylov-Schur step with block size 1): the tile width that spreads the m columns evenly over the
+  // four wavefronts and the fewest passes, e.g. m = 100 -> 4 passes of 7 columns (15 tiles), not 13 tiles of 8
+  const int passes = (m + 31) / 32, lt1 = std::max(1, (m + 4 * passes - 1) / (4 * passes));
   if (cplx) {
-    if (k >= 4) launch_trans_mv<4, 4, true>(c, gx, Ad, Td, m, k);
-    else if (k >= 2) launch_trans_mv<8, 2, true>(c, gx, Ad, Td, m, k);
-    else launch_trans_mv<16, 1, true>(c, gx, Ad, Td, m, k);
+    if (k >= 4) launch_trans_mv<4, 4, true>(c, gx, Ad, A2d, Td, m, k);
+    else if (k >= 2) launch_trans_mv<8, 2, true>(c, gx, Ad, A2d, Td, m, k);
+    else switch (lt1) {
+      case 1: launch_trans_mv<1, 1, true>(c, gx, Ad, A2d, Td, m, k); break;
+      case 2: launch_trans_mv<2, 1, true>(c, gx, Ad, A2d, Td, m, k); break;
+      case 3: launch_trans_mv<3, 1, true>(c, gx, Ad, A2d, Td, m, k); break;
+      case 4: launch_trans_mv<4, 1, true>(c, gx, Ad, A2d, Td, m, k); break;
+      case 5: launch_trans_mv<5, 1, true>(c, gx, Ad, A2d, Td, m, k); break;
+      case 6: launch_trans_mv<6, 1, true>(c, gx, Ad, A2d, Td, m, k); break;
+      case 7: launch_trans_mv<7, 1, true>(c, gx, Ad, A2d, Td, m, k); break;
+      default: launch_trans_mv<8, 1, true>(c, gx, Ad, A2d, Td, m, k); break;
+    }
   } else {
-    if (k >= 8) launch_trans_mv<4, 8, false>(c, gx, Ad, Td, m, k);
-    else if (k >= 4) launch_trans_mv<8, 4, false>(c, gx, Ad, Td, m, k);
-    else if (k >= 2) launch_trans_mv<16, 2, false>(c, gx, Ad, Td, m, k);
-    else launch_trans_mv<32, 1, false>(c, gx, Ad, Td, m, k);
+    if (k >= 8) launch_trans_mv<4, 8, false>(c, gx, Ad, A2d, Td, m, k);
+    else if (k >= 4) launch_trans_mv<8, 4, false>(c, gx, Ad, A2d, Td, m, k);
+    else if (k >= 2) launch_trans_mv<8, 2, false>(c, gx, Ad, A2d, Td, m, k);
+    else switch (lt1) {
+      case 1: launch_trans_mv<1, 1, false>(c, gx, Ad, A2d, Td, m, k); break;
+      case 2: launch_trans_mv<2, 1, false>(c, gx, Ad, A2d, Td, m, k); break;
+      case 3: launch_trans_mv<3, 1, false>(c, gx, Ad, A2d, Td, m, k); break;
+      case 4: launch_trans_mv<4, 1, false>(c, gx, Ad, A2d, Td, m, k); break;
+      case 5: launch_trans_mv<5, 1, false>(c, gx, Ad, A2d, Td, m, k); break;
+      case 6: launch_trans_mv<6, 1, false>(c, gx, Ad, A2d, Td, m, k); break;
+      case 7: launch_trans_mv<7, 1, false>(c, gx, Ad, A2d, Td, m, k); break;
+      default: launch_trans_mv<8, 1, false>(c, gx, Ad, A2d, Td, m, k); break;
+    }
   }
   hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)width), dim3(BLK), 0, c->stream, c->d_partial, gx,
                      c->d_result);
@@ -674,4 +758,9 @@ extern "C" int mxg_mv_trans_mv(double alr, double ali, const mxg_mv* A, const mx
       }
     }
   return 0;
+}
+
+extern "C" int mxg_mv_trans_mv(double alr, double ali, const mxg_mv* A, const mxg_mv* self,
+                               double* B, int ldb) {
+  return mxg_mv_trans_mv2(alr, ali, A, nullptr, self, B, ldb);
 }

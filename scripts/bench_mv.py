@@ -18,7 +18,7 @@ def timed(name, fn, nbytes):
                     frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 3)))
     print(out[-1], flush=True)
 
-for m, k in ((30, 1), (30, 4), (100, 1)):
+for m, k in ((30, 1), (30, 4), (100, 1), (10, 1), (30, 8)):
     V = mx.MultiVec(ctx, n, m); V.random(1)
     W = mx.MultiVec(ctx, n, k); W.random(2)
     Z = mx.MultiVec(ctx, n, k); Z.random(3)
@@ -32,4 +32,6 @@ for m, k in ((30, 1), (30, 4), (100, 1)):
     timed("trans_mv m=%d k=%d" % (m, k), lambda: W.trans_mv(1.0, V), 8 * n * (m + k))
     timed("times_mat m=%d k=%d (beta=1)" % (m, k), lambda: W.times_mat_add_mv(1e-9, V, B, 1.0), 8 * n * (m + 2 * k))
     del V, W, Z
-json.dump(out, open("gpurun_out/bench_mv.json", "w"), indent=1)
+outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+os.makedirs(outdir, exist_ok=True)
+json.dump(out, open(os.path.join(outdir, "bench_mv.json"), "w"), indent=1)

@@ -1,11 +1,12 @@
-# rocprofv3 kernel breakdown of the 256^3 eigen-solve (multigrid-CG inner solves)
-TAG=${1:-r01c}
+# rocprofv3 kernel statistics of the 256^3 eigen-solve alone (no SpMV timing loop, no CPU baseline).
+# Usage (on the GPU box, from the repo root): bash scripts/gpu_prof_eigen.sh <tag>
+TAG=${1:-r02}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 800 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eigen_$TAG -- python $ROOT/bench.py --steps 5 --warmup 2 --eig-n ${EIGN:-256} --cpu-seconds 0 > $OUT/prof_eigen_$TAG.log 2>&1
-rc=$?; tail -3 $OUT/prof_eigen_$TAG.log | cut -c1-600
+MXH_VERBOSE=1 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eigen_$TAG -- python $ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-compressed > $OUT/prof_eigen_$TAG.log 2>&1
+rc=$?; echo "rc=$rc"; tail -3 $OUT/prof_eigen_$TAG.log
 f=$(find $OUT/prof_eigen_$TAG -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp $f $OUT/eigen_kernel_stats_$TAG.csv && cut -d, -f2-5 $f | head -25
-rm -rf $OUT/prof_eigen_$TAG      # the per-dispatch trace is hundreds of MiB; only the summary is kept
-exit $rc
+[ -n "$f" ] && cp $f $OUT/eigen_kernel_stats_$TAG.csv && head -30 $f
+# the kernel trace itself is large: keep only the statistics
+find $OUT/prof_eigen_$TAG -name "*kernel_trace.csv" -delete

@@ -51,7 +51,7 @@ def test_blas1(ctx, rng, cx, n):
 
 
 @pytest.mark.parametrize("cx", [False, True])
-@pytest.mark.parametrize("m,k", [(1, 1), (5, 1), (40, 1), (7, 2), (20, 3), (33, 8), (12, 16)])
+@pytest.mark.parametrize("m,k", [(1, 1), (5, 1), (40, 1), (7, 2), (20, 3), (33, 8), (12, 16), (30, 4), (100, 1), (101, 5)])
 def test_block_products(ctx, rng, cx, m, k):
     """K6 MvTimesMatAddMv and K7 MvTransMv for the shapes the solvers use."""
     n = 20011
@@ -68,6 +68,29 @@ def test_block_products(ctx, rng, cx, m, k):
     Y2 = mx.MultiVec.from_numpy(ctx, np.full((n, k), np.nan + 0j if cx else np.nan))
     Y2.times_mat_add_mv(1.0, A, Bm, 0.0)
     assert np.abs(Y2.to_numpy() - a @ Bm).max() <= 1e-13 * m
+
+
+@pytest.mark.parametrize("cx", [False, True])
+@pytest.mark.parametrize("n", [1, 64, 1001, 300007])
+def test_trans_mv_with_appended_columns_and_repeated_reductions(ctx, rng, cx, n):
+    """mxg_mv_trans_mv2: [A A2]^H T from one pass (the Krylov-Schur step takes V^H w and w^H w together), A a view of
+    scattered columns; and dot / norm2 many times in a row: the second stage adds the partials in block order and stores
+    into the pinned host buffer, every repetition returns the same bits."""
+    m, k = 13, 3
+    a, t = _rand(rng, n, m + 4, cx), _rand(rng, n, k, cx)
+    A, T = mx.MultiVec.from_numpy(ctx, a), mx.MultiVec.from_numpy(ctx, t)
+    cols = [3, 0, 16, 7, 8, 9, 10, 2, 1, 11, 12, 14, 5]
+    got = T.trans_mv(1.0, A.view(cols), T)
+    ref = np.conj(np.hstack([a[:, cols], t])).T @ t
+    assert got.shape == (m + k, k) and np.abs(got - ref).max() <= TOL * max(n, 16)
+    sep = T.trans_mv(1.0, A.view(cols))
+    assert np.array_equal(got[:m], sep)                       # same kernel, same order of additions
+    first_d, first_n = T.dot(T), T.norm2()
+    assert np.abs(first_n - np.sqrt(np.abs(np.diag(got[m:])))).max() <= 1e-12 * max(1.0, np.sqrt(n))
+    for _ in range(20):
+        assert np.array_equal(T.dot(T), first_d) and np.array_equal(T.norm2(), first_n)
+    u = mx.MultiVec.from_numpy(ctx, _rand(rng, n, k, cx))
+    assert np.abs(u.dot(T) - cref.mv_dot(T.to_numpy(), u.to_numpy())).max() <= TOL * max(n, 16)
 
 
 def test_views_clone_setblock(ctx, rng):
