@@ -127,7 +127,10 @@ class MxCrsMatrix {
   // y = A x on the GPU; x may alias y (src/MxMagWaveOp.cpp:650,1249)
   void apply(MxMultiVector<Scalar> const& x, MxMultiVector<Scalar>& y) const {
     if (!mFilled) { std::cout << "MxCrsMatrix::apply: matrix is not fill-completed\n"; throw 1; }
-    ensureDevice();
+    // the compressed stream costs a host-side encoding pass (about 1 s for a 256^3 operator): operators the hot loop
+    // uses are encoded at setup (getRawMatrix), anything else once it has been applied a few times - the one-off
+    // products of the post-processing (curlCurl, curlB in checkEigensolution / magToElec) stay plain CSR
+    ensureDevice(++mApplies > 3);
     MX_ABI(mxg_csr_apply(mRowMap->getComm()->getCtx(), mDev, x.raw(), y.raw()), "MxCrsMatrix::apply");
   }
 
@@ -436,6 +439,7 @@ class MxCrsMatrix {
   mutable mx::Csr<Scalar> mHost;     // (filled on demand for a matrix formed on the device: host())
   mutable bool mHostValid = true;
   mutable bool mCompressed = false;
+  mutable int mApplies = 0;
   mutable mxg_csr* mDev;
 };
 

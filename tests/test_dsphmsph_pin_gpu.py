@@ -13,7 +13,7 @@ Per table entry (a mode of a class; degenerate members each count):
   * TM entries (E normal to the dielectric surface) carry a small FIRST-order term besides the second-order one
     (a ~ 0.1 on TM_01): the scheme's own behaviour on a curved interface - the same stencil reproduces a
     piecewise-constant field across a tilted planar interface exactly and is second order on an axis-aligned
-    slab (tests/test_oracle.py), and the term survives exact (arc instead of chord) area fractions - see
+    slab (tests/test_dsphmsph_pin.py), and the term survives exact (arc instead of chord) area fractions - see
     DESIGN.md section 5.  Their observed order is asserted to lie in [0.9, 2.3] and recorded, not forced to 2.
 Also checked: the three frequencies the reference's octModes(['pec']*3, 5) returns.
 """
