@@ -144,6 +144,9 @@ struct mxg_csr {
   void* d_patdict = nullptr;
   int32_t* d_grows = nullptr;
   int64_t pat_npat = 0, pat_ngrows = 0, pat_gnnz = 0;
+  unsigned short* d_pairid = nullptr;   // row-pair form of the pattern product (mxg_pat.hip): id per pair of rows
+  void* d_pairdict = nullptr;
+  int64_t pat_npair = 0;
   int64_t cs_pattern_rows = 0;   // rows encoded as one pattern id (persistent kernel's records)
   int64_t ncs_interior = 0;      // compressed descriptors [0, ncs_interior) reference no ghost column
   // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
@@ -197,6 +200,7 @@ int mxg_dev_csr_apply_dot(mxg_ctx* ctx, mxg_csr* a, const mxg_mv* x, mxg_mv* y, 
 
 // pattern-dictionary product (mxg_pat.hip)
 int mxg_pat_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
+int mxg_pair_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
 int64_t mxg_pat_partials(const mxg_csr* a);
 int mxg_pat_launch(mxg_ctx* c, mxg_csr* a, const double* x, double* y, int epi, int dot, const double* xdot,
                    double* partial, const double* rhs, const double* diag, double omega, double beta, int halo,

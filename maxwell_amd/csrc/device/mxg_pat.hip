@@ -119,6 +119,381 @@ __global__ __launch_bounds__(PAT_BLOCK) void k_spmv_pat(
   if (DOT) pat_block_sum(part, partial, b);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-persistent form of the same product ("patw").  scripts/ubench_gather.hip showed that a bare 7-point stencil
+// over this numbering runs in 0.077 ms for 20.6 M rows (0.054 ms with 16-byte gathers) - the x gathers are not what
+// costs 0.2 ms in k_spmv_cs / k_spmv_pat; the per-row vector-memory and LDS instructions that fetch and decode the
+// matrix are (k_spmv_pat: 7 dictionary loads + 8 gathers per row).  On the Yee lattice a row's pattern is that of the
+// row three before it (same component, next cell of the grid line) for hundreds of rows, so: each wavefront owns a
+// contiguous range of rows and walks it in tiles of 63 rows (a multiple of the three interleaved components, lane l
+// always meets the same component); a lane keeps its pattern - column offsets and values - in registers and reloads
+// it only when the 2-byte id of its next row differs from the cached one (line ends, the cavity wall).  Per row that
+// leaves the id, the gathers (as many as the longest row of the tile has entries) and the store.
+// Values, offsets and the order of the row sum are those of the dictionary = of the CSR arrays: bit-identical.
+constexpr int PATW_TILE = 63;
+constexpr int PATW_WAVES = 4;          // wavefronts per workgroup
+
+__device__ inline long long patw_rows_per_wave(long long nrows, long long nwaves) {
+  const long long tiles = (nrows + PATW_TILE - 1) / PATW_TILE;
+  return ((tiles + nwaves - 1) / nwaves) * PATW_TILE;
+}
+
+template <bool DOT, int EPI, bool HALO>
+__global__ __launch_bounds__(64 * PATW_WAVES) void k_spmv_patw(
+    const unsigned short* __restrict__ rowpid, const PatEntry* __restrict__ dict, long long nrows, long long nwgs,
+    const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ xdot, double* __restrict__ partial,
+    const double* __restrict__ rhs, const double* __restrict__ diag, double omega, double beta,
+    const double* __restrict__ xg, long long nowned) {
+  const long long wg = pat_xcd_block(blockIdx.x, nwgs);          // XCD w % 8 walks a contiguous eighth of the rows
+  if (wg >= nwgs) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long gw = wg * PATW_WAVES + wave;
+  const long long per = patw_rows_per_wave(nrows, nwgs * PATW_WAVES);
+  const long long r_begin = gw * per, r_end = min(nrows, r_begin + per);
+  unsigned cpid = PAT_NONE;                                      // id of the pattern held in dl / v / len
+  int dl[PAT_LEN];
+  double v[PAT_LEN];
+  int len = 0;
+#pragma unroll
+  for (int i = 0; i < PAT_LEN; ++i) { dl[i] = 0; v[i] = 0.0; }
+  double part = 0.0;
+  const bool live = lane < PATW_TILE;
+  long long row = r_begin + lane;
+  unsigned pid = (live && row < r_end) ? (unsigned)rowpid[row] : (unsigned)PAT_NONE;
+  for (long long base = r_begin; base < r_end; base += PATW_TILE) {
+    row = base + lane;
+    const bool act = live && row < r_end && pid != PAT_NONE;
+    // the id of this lane's row in the next tile: in flight while this tile is processed
+    const long long nrow = row + PATW_TILE;
+    const unsigned npid = (live && nrow < r_end) ? (unsigned)rowpid[nrow] : (unsigned)PAT_NONE;
+    if (act && pid != cpid) {                                    // exec-masked reload: rare
+      const PatEntry* e = dict + pid;
+      const uint4p d0 = *reinterpret_cast<const uint4p*>(e->delta), d1 = *reinterpret_cast<const uint4p*>(e->delta + 4);
+      const dbl2p v01 = *reinterpret_cast<const dbl2p*>(e->val), v23 = *reinterpret_cast<const dbl2p*>(e->val + 2),
+                  v45 = *reinterpret_cast<const dbl2p*>(e->val + 4), v67 = *reinterpret_cast<const dbl2p*>(e->val + 6);
+      len = e->len;
+      dl[0] = (int)d0.x; dl[1] = (int)d0.y; dl[2] = (int)d0.z; dl[3] = (int)d0.w;
+      dl[4] = (int)d1.x; dl[5] = (int)d1.y; dl[6] = (int)d1.z; dl[7] = (int)d1.w;
+      v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y; v[4] = v45.x; v[5] = v45.y; v[6] = v67.x; v[7] = v67.y;
+      cpid = pid;
+    }
+    const int mylen = act ? len : 0;
+    int maxlen = mylen;                                          // wave-uniform trip count of the gather loop
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+    if (maxlen > 0) {
+      double xv[PAT_LEN];
+#pragma unroll
+      for (int i = 0; i < PAT_LEN; ++i) {
+        if (i < maxlen) {                                        // uniform branch; lanes past their end re-read entry 0
+          const long long cc = act ? row + (i < mylen ? dl[i] : dl[0]) : 0;
+          xv[i] = (HALO && cc >= nowned) ? xg[cc - nowned] : x[cc];
+        }
+      }
+      if (act) {
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < PAT_LEN; ++i) {
+          if (i < maxlen) {
+            const double s2 = sum + v[i] * xv[i];
+            sum = i < mylen ? s2 : sum;
+          }
+        }
+        __builtin_nontemporal_store(pat_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y), y + row);
+        if (DOT) part += sum * xdot[row];
+      }
+    }
+    pid = npid;
+  }
+  if (DOT) {                                                     // one partial per wavefront, lanes added in lane order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) partial[gw] = part;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-pair form ("pair", MXG_PAT=2).  scripts/ubench_gather.hip: the floor of these kernels is the number of vector-
+// memory instructions per row (a wave64 load or store costs a CU ~18 cycles whatever it hits), and a bare stencil
+// with 16-byte gathers runs at the HBM rate of x + y.  Two consecutive rows (2m, 2m+1: different components of
+// the same or the next cell) have the SAME column offsets wherever the lattice is regular, so one 16-byte gather
+// serves both: the dictionary holds pair patterns (shared offsets, two value lists), a lane handles PAIR_U pairs at
+// stride 63 pairs (a multiple of the three interleaved components: the same pattern for hundreds of rows along a
+// grid line), loads the pattern once and issues all PAIR_U x len gathers before the first product.  Pairs whose id
+// differs from the lane's first one take a second, masked pass; rows that do not pair stay individual (k_spmv_gen).
+// Per row: (PAIR_U + 10 + PAIR_U len + PAIR_U) / (2 PAIR_U) = 5.75 vector-memory instructions at len 7 instead of
+// 17 (k_spmv_pat).  Values, offsets and the order of each row sum are those of the CSR arrays: bit-identical.
+struct PairEntry {                // 256 bytes
+  int delta[PAT_LEN];             // column - row, the same for both rows of the pair
+  double va[PAT_LEN];             // values of row 2m
+  double vb[PAT_LEN];             // values of row 2m + 1
+  int len, pad[23];
+};
+static_assert(sizeof(PairEntry) == 256, "pair dictionary entry layout");
+constexpr int PAIR_TILE = 63, PAIR_WAVES = 4;
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte access at 8-byte alignment
+
+struct PairRegs { int dl[PAT_LEN]; double va[PAT_LEN], vb[PAT_LEN]; int len; };
+
+__device__ inline void pair_load(const PairEntry* __restrict__ e, PairRegs& R) {
+  const uint4p d0 = *reinterpret_cast<const uint4p*>(e->delta), d1 = *reinterpret_cast<const uint4p*>(e->delta + 4);
+  R.dl[0] = (int)d0.x; R.dl[1] = (int)d0.y; R.dl[2] = (int)d0.z; R.dl[3] = (int)d0.w;
+  R.dl[4] = (int)d1.x; R.dl[5] = (int)d1.y; R.dl[6] = (int)d1.z; R.dl[7] = (int)d1.w;
+#pragma unroll
+  for (int i = 0; i < PAT_LEN; i += 2) {
+    const dbl2p a = *reinterpret_cast<const dbl2p*>(e->va + i), b = *reinterpret_cast<const dbl2p*>(e->vb + i);
+    R.va[i] = a.x; R.va[i + 1] = a.y; R.vb[i] = b.x; R.vb[i + 1] = b.y;
+  }
+  R.len = e->len;
+}
+
+// epilogue of both rows of a pair (row = 2m, 16-byte aligned accesses); same arithmetic as pat_epilogue
+template <int EPI>
+__device__ inline dbl2p pair_epilogue(dbl2p ax, long long row, const double* __restrict__ x, const double* __restrict__ rhs,
+                                      const double* __restrict__ diag, double omega, double beta, const double* y) {
+  dbl2p o;
+  if (EPI == 0) return ax;
+  if (EPI == 2) { const dbl2p r = *reinterpret_cast<const dbl2p*>(rhs + row); o.x = r.x - ax.x; o.y = r.y - ax.y; return o; }
+  if (EPI == 3) { const dbl2p yy = *reinterpret_cast<const dbl2p*>(y + row); o.x = yy.x + omega * ax.x; o.y = yy.y + omega * ax.y; return o; }
+  const dbl2p dg = *reinterpret_cast<const dbl2p*>(diag + row), xr = *reinterpret_cast<const dbl2p*>(x + row),
+              r = *reinterpret_cast<const dbl2p*>(rhs + row);
+  if (EPI == 1) {
+    o.x = dg.x != 0.0 ? xr.x + omega * (r.x - ax.x) / dg.x : xr.x;
+    o.y = dg.y != 0.0 ? xr.y + omega * (r.y - ax.y) / dg.y : xr.y;
+  } else if (EPI == 5) {
+    o.x = dg.x != 0.0 ? xr.x + beta * xr.x + omega * (r.x - ax.x) / dg.x : xr.x;
+    o.y = dg.y != 0.0 ? xr.y + beta * xr.y + omega * (r.y - ax.y) / dg.y : xr.y;
+  } else {   // EPI == 4
+    const dbl2p yy = *reinterpret_cast<const dbl2p*>(y + row);
+    o.x = dg.x != 0.0 ? xr.x + beta * (xr.x - yy.x) + omega * (r.x - ax.x) / dg.x : xr.x;
+    o.y = dg.y != 0.0 ? xr.y + beta * (xr.y - yy.y) + omega * (r.y - ax.y) / dg.y : xr.y;
+  }
+  return o;
+}
+
+template <bool DOT, int EPI, int PAIR_U>
+__global__ __launch_bounds__(64 * PAIR_WAVES) void k_spmv_pair(
+    const unsigned short* __restrict__ pairid, const PairEntry* __restrict__ dict, long long npairs, long long nwgs,
+    const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ xdot, double* __restrict__ partial,
+    const double* __restrict__ rhs, const double* __restrict__ diag, double omega, double beta) {
+  const long long wg = pat_xcd_block(blockIdx.x, nwgs);          // XCD w % 8 walks a contiguous eighth of the rows
+  if (wg >= nwgs) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long gw = wg * PAIR_WAVES + wave;
+  const long long m0 = gw * (long long)(PAIR_TILE * PAIR_U);
+  const bool live = lane < PAIR_TILE;
+  long long m[PAIR_U];
+  unsigned pid[PAIR_U];
+#pragma unroll
+  for (int u = 0; u < PAIR_U; ++u) {
+    m[u] = m0 + (long long)u * PAIR_TILE + lane;
+    pid[u] = (live && m[u] < npairs) ? (unsigned)pairid[m[u]] : (unsigned)PAT_NONE;
+  }
+  double part = 0.0;
+  PairRegs R;
+  R.len = 0;
+  // ---- pass 1: every pair of this lane that carries the id of its first one
+  const unsigned cur = pid[0];
+  if (cur != PAT_NONE) pair_load(dict + cur, R);
+  const int mylen = cur != PAT_NONE ? R.len : 0;
+  int maxlen = mylen;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+  bool fast[PAIR_U];
+#pragma unroll
+  for (int u = 0; u < PAIR_U; ++u) fast[u] = cur != PAT_NONE && pid[u] == cur;
+  {
+    dbl2p xv[PAIR_U][PAT_LEN];
+#pragma unroll
+    for (int u = 0; u < PAIR_U; ++u)
+#pragma unroll
+      for (int i = 0; i < PAT_LEN; ++i)
+        if (i < maxlen) {                                        // wave-uniform; lanes past their end re-read entry 0
+          const long long cc = (fast[u] && mylen > 0) ? 2 * m[u] + (i < mylen ? R.dl[i] : R.dl[0]) : 0;   // empty pair: x[0]
+          const dbl2u t = *reinterpret_cast<const dbl2u*>(x + cc);
+          xv[u][i].x = t.x; xv[u][i].y = t.y;
+        }
+#pragma unroll
+    for (int u = 0; u < PAIR_U; ++u)
+      if (fast[u]) {
+        dbl2p sum; sum.x = 0.0; sum.y = 0.0;
+#pragma unroll
+        for (int i = 0; i < PAT_LEN; ++i)
+          if (i < maxlen) {
+            const double sa = sum.x + R.va[i] * xv[u][i].x, sb = sum.y + R.vb[i] * xv[u][i].y;
+            sum.x = i < mylen ? sa : sum.x;
+            sum.y = i < mylen ? sb : sum.y;
+          }
+        const long long row = 2 * m[u];
+        __builtin_nontemporal_store(pair_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y), reinterpret_cast<dbl2p*>(y + row));
+        if (DOT) { const dbl2p xd = *reinterpret_cast<const dbl2p*>(xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+      }
+  }
+  // ---- pass 2 (line ends, the cavity wall): pairs with another id, one at a time under the lane mask
+#pragma unroll
+  for (int u = 1; u < PAIR_U; ++u) {
+    const bool need = pid[u] != PAT_NONE && !fast[u];
+    if (__any(need)) {
+      if (need) {
+        pair_load(dict + pid[u], R);
+        dbl2p xv[PAT_LEN];
+#pragma unroll
+        for (int i = 0; i < PAT_LEN; ++i) {
+          const long long cc = R.len > 0 ? 2 * m[u] + (i < R.len ? R.dl[i] : R.dl[0]) : 0;
+          const dbl2u t = *reinterpret_cast<const dbl2u*>(x + cc);
+          xv[i].x = t.x; xv[i].y = t.y;
+        }
+        dbl2p sum; sum.x = 0.0; sum.y = 0.0;
+#pragma unroll
+        for (int i = 0; i < PAT_LEN; ++i) {
+          const double sa = sum.x + R.va[i] * xv[i].x, sb = sum.y + R.vb[i] * xv[i].y;
+          sum.x = i < R.len ? sa : sum.x;
+          sum.y = i < R.len ? sb : sum.y;
+        }
+        const long long row = 2 * m[u];
+        __builtin_nontemporal_store(pair_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y), reinterpret_cast<dbl2p*>(y + row));
+        if (DOT) { const dbl2p xd = *reinterpret_cast<const dbl2p*>(xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+      }
+    }
+  }
+  if (DOT) {                                                     // one partial per wavefront, lanes added in lane order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) partial[gw] = part;
+  }
+}
+
+// Wave-persistent form of the pair product (MXG_PAIRW=1; the default is k_spmv_pair): a wavefront owns a contiguous
+// range of pairs and walks it PAIRW_U tiles of 63 pairs at a time; a lane keeps its pair pattern in registers and
+// reloads it only when an id differs from the cached one; the ids of the next step are fetched while the gathers of
+// this one are in flight, so a step is ONE memory round trip (the gathers) instead of three (id -> pattern -> gathers).
+constexpr int PAIRW_U = 2;
+
+__device__ inline long long pairw_pairs_per_wave(long long npairs, long long nwaves) {
+  const long long step = (long long)PAIR_TILE * PAIRW_U;
+  const long long steps = (npairs + step - 1) / step;
+  return ((steps + nwaves - 1) / nwaves) * step;
+}
+
+template <bool DOT, int EPI>
+__global__ __launch_bounds__(64 * PAIR_WAVES) void k_spmv_pairw(
+    const unsigned short* __restrict__ pairid, const PairEntry* __restrict__ dict, long long npairs, long long nwgs,
+    const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ xdot, double* __restrict__ partial,
+    const double* __restrict__ rhs, const double* __restrict__ diag, double omega, double beta) {
+  const long long wg = pat_xcd_block(blockIdx.x, nwgs);
+  if (wg >= nwgs) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long gw = wg * PAIR_WAVES + wave;
+  const long long per = pairw_pairs_per_wave(npairs, nwgs * PAIR_WAVES);
+  const long long m_begin = gw * per, m_end = min(npairs, m_begin + per);
+  const bool live = lane < PAIR_TILE;
+  PairRegs R;
+  R.len = 0;
+#pragma unroll
+  for (int i = 0; i < PAT_LEN; ++i) { R.dl[i] = 0; R.va[i] = 0.0; R.vb[i] = 0.0; }
+  unsigned cpid = PAT_NONE;
+  double part = 0.0;
+  unsigned pid[PAIRW_U];
+#pragma unroll
+  for (int u = 0; u < PAIRW_U; ++u) {
+    const long long mm = m_begin + (long long)u * PAIR_TILE + lane;
+    pid[u] = (live && mm < m_end) ? (unsigned)pairid[mm] : (unsigned)PAT_NONE;
+  }
+  for (long long base = m_begin; base < m_end; base += (long long)PAIR_TILE * PAIRW_U) {
+    long long m[PAIRW_U];
+    unsigned npid[PAIRW_U];
+#pragma unroll
+    for (int u = 0; u < PAIRW_U; ++u) {
+      m[u] = base + (long long)u * PAIR_TILE + lane;
+      const long long nm = m[u] + (long long)PAIR_TILE * PAIRW_U;
+      npid[u] = (live && nm < m_end) ? (unsigned)pairid[nm] : (unsigned)PAT_NONE;   // in flight during this step
+    }
+    // the lane's pattern: that of its first live pair of this step; reload only on a change
+    unsigned want = PAT_NONE;
+#pragma unroll
+    for (int u = PAIRW_U - 1; u >= 0; --u) want = pid[u] != PAT_NONE ? pid[u] : want;
+    if (want != PAT_NONE && want != cpid) { pair_load(dict + want, R); cpid = want; }
+    bool fast[PAIRW_U];
+    bool anyfast = false;
+#pragma unroll
+    for (int u = 0; u < PAIRW_U; ++u) { fast[u] = pid[u] != PAT_NONE && pid[u] == cpid; anyfast = anyfast || fast[u]; }
+    const int mylen = anyfast ? R.len : 0;
+    int maxlen = mylen;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+    if (maxlen > 0) {
+      dbl2p xv[PAIRW_U][PAT_LEN];
+#pragma unroll
+      for (int u = 0; u < PAIRW_U; ++u)
+#pragma unroll
+        for (int i = 0; i < PAT_LEN; ++i)
+          if (i < maxlen) {
+            const long long cc = (fast[u] && mylen > 0) ? 2 * m[u] + (i < mylen ? R.dl[i] : R.dl[0]) : 0;   // empty pair: x[0]
+            const dbl2u t = *reinterpret_cast<const dbl2u*>(x + cc);
+            xv[u][i].x = t.x; xv[u][i].y = t.y;
+          }
+#pragma unroll
+      for (int u = 0; u < PAIRW_U; ++u)
+        if (fast[u]) {
+          dbl2p sum; sum.x = 0.0; sum.y = 0.0;
+#pragma unroll
+          for (int i = 0; i < PAT_LEN; ++i)
+            if (i < maxlen) {
+              const double sa = sum.x + R.va[i] * xv[u][i].x, sb = sum.y + R.vb[i] * xv[u][i].y;
+              sum.x = i < mylen ? sa : sum.x;
+              sum.y = i < mylen ? sb : sum.y;
+            }
+          const long long row = 2 * m[u];
+          __builtin_nontemporal_store(pair_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y), reinterpret_cast<dbl2p*>(y + row));
+          if (DOT) { const dbl2p xd = *reinterpret_cast<const dbl2p*>(xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+        }
+    } else if (anyfast) {                                      // empty pairs: the epilogue of a zero product
+#pragma unroll
+      for (int u = 0; u < PAIRW_U; ++u)
+        if (fast[u]) {
+          dbl2p sum; sum.x = 0.0; sum.y = 0.0;
+          const long long row = 2 * m[u];
+          __builtin_nontemporal_store(pair_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y), reinterpret_cast<dbl2p*>(y + row));
+        }
+    }
+    // pairs of this step with another id than the cached one (line ends, the wall): one at a time under the lane mask
+#pragma unroll
+    for (int u = 1; u < PAIRW_U; ++u) {
+      const bool need = pid[u] != PAT_NONE && !fast[u];
+      if (__any(need)) {
+        if (need) {
+          pair_load(dict + pid[u], R);
+          cpid = pid[u];
+          dbl2p xw[PAT_LEN];
+#pragma unroll
+          for (int i = 0; i < PAT_LEN; ++i) {
+            const long long cc = R.len > 0 ? 2 * m[u] + (i < R.len ? R.dl[i] : R.dl[0]) : 0;
+            const dbl2u t = *reinterpret_cast<const dbl2u*>(x + cc);
+            xw[i].x = t.x; xw[i].y = t.y;
+          }
+          dbl2p sum; sum.x = 0.0; sum.y = 0.0;
+#pragma unroll
+          for (int i = 0; i < PAT_LEN; ++i) {
+            const double sa = sum.x + R.va[i] * xw[i].x, sb = sum.y + R.vb[i] * xw[i].y;
+            sum.x = i < R.len ? sa : sum.x;
+            sum.y = i < R.len ? sb : sum.y;
+          }
+          const long long row = 2 * m[u];
+          __builtin_nontemporal_store(pair_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y), reinterpret_cast<dbl2p*>(y + row));
+          if (DOT) { const dbl2p xd = *reinterpret_cast<const dbl2p*>(xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PAIRW_U; ++u) pid[u] = npid[u];
+  }
+  if (DOT) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) partial[gw] = part;
+  }
+}
+
 // the individual rows: one thread per row over the CSR arrays, entries in storage order
 template <bool DOT, int EPI, bool HALO>
 __global__ __launch_bounds__(PAT_BLOCK) void k_spmv_gen(
@@ -133,17 +508,21 @@ __global__ __launch_bounds__(PAT_BLOCK) void k_spmv_gen(
     const long long row = grows[i];
     const long long q0 = rowptr[row], q1 = rowptr[row + 1];
     double sum = 0.0;
-    for (long long q = q0; q < q1; q += 4) {              // gathers in batches of four, products in storage order
-      double vv[4], xx[4];
+    // 8 entries per trip: all columns and values first, then all gathers (two memory round trips per 8 entries),
+    // products in storage order
+    for (long long q = q0; q < q1; q += 8) {
+      double vv[8], xx[8];
+      int cc[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 8; ++j) {
         const long long qq = q + j < q1 ? q + j : q1 - 1;
-        const long long cc = colidx[qq];
+        cc[j] = colidx[qq];
         vv[j] = vals[qq];
-        xx[j] = (HALO && cc >= nowned) ? xg[cc - nowned] : x[cc];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 8; ++j) xx[j] = (HALO && cc[j] >= nowned) ? xg[cc[j] - nowned] : x[cc[j]];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
         const double s2 = sum + vv[j] * xx[j];
         sum = q + j < q1 ? s2 : sum;
       }
@@ -154,12 +533,65 @@ __global__ __launch_bounds__(PAT_BLOCK) void k_spmv_gen(
   if (DOT) pat_block_sum(part, partial, blockIdx.x);
 }
 
+// MXG_PATW=0 selects the one-thread-per-row kernel (k_spmv_pat)
+bool patw_on() { static const bool on = !(getenv("MXG_PATW") && atoi(getenv("MXG_PATW")) == 0); return on; }
+// workgroups of the wave-persistent kernel: MXG_PATW_WGS per CU (default 4 = 16 wavefronts per CU), but never so many
+// that a wavefront would own fewer than 8 tiles
+long long patw_wgs(const mxg_ctx* c, const mxg_csr* a) {
+  static const int per_cu = getenv("MXG_PATW_WGS") ? std::max(1, atoi(getenv("MXG_PATW_WGS"))) : 4;
+  const long long tiles = (a->nrows + PATW_TILE - 1) / PATW_TILE;
+  long long wgs = (long long)c->num_cu * per_cu;
+  wgs = std::min(wgs, std::max<long long>(1, tiles / (8 * PATW_WAVES)));
+  return wgs;
+}
+// pairs per lane of the one-shot pair kernel (MXG_PAIR_U = 2, 3 or 4)
+int pair_u() { static const int u = getenv("MXG_PAIR_U") ? std::min(4, std::max(2, atoi(getenv("MXG_PAIR_U")))) : 2; return u; }
+bool pairw_on() { static const bool on = getenv("MXG_PAIRW") && atoi(getenv("MXG_PAIRW")) != 0; return on; }
+long long pair_wgs(const mxg_ctx* c, const mxg_csr* a) {
+  if (pairw_on()) {          // MXG_PAIRW_WGS workgroups per CU (default 4), at least 8 steps per wavefront
+    static const int per_cu = getenv("MXG_PAIRW_WGS") ? std::max(1, atoi(getenv("MXG_PAIRW_WGS"))) : 4;
+    const long long steps = (a->nrows / 2 + PAIR_TILE * PAIRW_U - 1) / (PAIR_TILE * PAIRW_U);
+    return std::min<long long>((long long)c->num_cu * per_cu, std::max<long long>(1, steps / (8 * PAIR_WAVES)));
+  }
+  const long long per_wg = (long long)PAIR_TILE * pair_u() * PAIR_WAVES;
+  return (a->nrows / 2 + per_wg - 1) / per_wg;
+}
+// partial sums the pattern kernel writes (the individual-row kernel appends its own behind them)
+long long pat_first_partials(const mxg_ctx* c, const mxg_csr* a) {
+  if (a->d_pairid) return pair_wgs(c, a) * PAIR_WAVES;
+  return patw_on() ? patw_wgs(c, a) * PATW_WAVES : (a->nrows + PAT_BLOCK - 1) / PAT_BLOCK;
+}
+
 template <bool DOT, int EPI, bool HALO>
 void launch_pat_t(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const double* xdot, double* partial,
                   const double* rhs, const double* diag, double omega, double beta, const double* xg, long long nowned,
                   bool pattern_rows, bool generic_rows) {
-  const long long nb = (a->nrows + PAT_BLOCK - 1) / PAT_BLOCK;
-  if (pattern_rows && nb > 0) {
+  const long long nb = a->d_pairid ? pair_wgs(c, a) : patw_on() ? patw_wgs(c, a) : (a->nrows + PAT_BLOCK - 1) / PAT_BLOCK;
+  if (pattern_rows && nb > 0 && a->d_pairid) {
+    if (HALO) { mxg_set_error("mxg_pat_launch: the row-pair product does not read ghosts"); return; }
+    const unsigned grid = (unsigned)(((nb + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
+    if (pairw_on())
+      hipLaunchKernelGGL((k_spmv_pairw<DOT, EPI>), dim3(grid), dim3(64 * PAIR_WAVES), 0, c->stream,
+                         (const unsigned short*)a->d_pairid, (const PairEntry*)a->d_pairdict, (long long)(a->nrows / 2), nb, x, y,
+                         xdot, partial, rhs, diag, omega, beta);
+    else if (pair_u() == 4)
+      hipLaunchKernelGGL((k_spmv_pair<DOT, EPI, 4>), dim3(grid), dim3(64 * PAIR_WAVES), 0, c->stream,
+                         (const unsigned short*)a->d_pairid, (const PairEntry*)a->d_pairdict, (long long)(a->nrows / 2), nb, x, y,
+                         xdot, partial, rhs, diag, omega, beta);
+    else if (pair_u() == 3)
+      hipLaunchKernelGGL((k_spmv_pair<DOT, EPI, 3>), dim3(grid), dim3(64 * PAIR_WAVES), 0, c->stream,
+                         (const unsigned short*)a->d_pairid, (const PairEntry*)a->d_pairdict, (long long)(a->nrows / 2), nb, x, y,
+                         xdot, partial, rhs, diag, omega, beta);
+    else
+      hipLaunchKernelGGL((k_spmv_pair<DOT, EPI, 2>), dim3(grid), dim3(64 * PAIR_WAVES), 0, c->stream,
+                         (const unsigned short*)a->d_pairid, (const PairEntry*)a->d_pairdict, (long long)(a->nrows / 2), nb, x, y,
+                         xdot, partial, rhs, diag, omega, beta);
+  } else if (pattern_rows && nb > 0 && patw_on()) {
+    const unsigned grid = (unsigned)(((nb + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
+    hipLaunchKernelGGL((k_spmv_patw<DOT, EPI, HALO>), dim3(grid), dim3(64 * PATW_WAVES), 0, c->stream,
+                       (const unsigned short*)a->d_rowpid, (const PatEntry*)a->d_patdict, (long long)a->nrows, nb, x, y,
+                       xdot, partial, rhs, diag, omega, beta, xg, nowned);
+  } else if (pattern_rows && nb > 0) {
     const unsigned grid = (unsigned)(((nb + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD);
     hipLaunchKernelGGL((k_spmv_pat<DOT, EPI, HALO>), dim3(grid), dim3(PAT_BLOCK), 0, c->stream,
                        (const unsigned short*)a->d_rowpid, (const PatEntry*)a->d_patdict, (long long)a->nrows, nb, x, y,
@@ -170,14 +602,14 @@ void launch_pat_t(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const doub
     const unsigned grid = (unsigned)((ng + PAT_BLOCK - 1) / PAT_BLOCK);
     hipLaunchKernelGGL((k_spmv_gen<DOT, EPI, HALO>), dim3(grid), dim3(PAT_BLOCK), 0, c->stream,
                        (const int*)a->d_grows, ng, (const long long*)a->d_rowptr, (const int*)a->d_colidx,
-                       (const double*)a->d_vals, x, y, xdot, DOT ? partial + nb : partial, rhs, diag, omega, beta, xg, nowned);
+                       (const double*)a->d_vals, x, y, xdot, DOT ? partial + pat_first_partials(c, a) : partial, rhs, diag, omega, beta, xg, nowned);
   }
 }
 
 }  // namespace
 
 int64_t mxg_pat_partials(const mxg_csr* a) {
-  return (a->nrows + PAT_BLOCK - 1) / PAT_BLOCK + (a->pat_ngrows + PAT_BLOCK - 1) / PAT_BLOCK;
+  return pat_first_partials(a->ctx, a) + (a->pat_ngrows + PAT_BLOCK - 1) / PAT_BLOCK;
 }
 
 // y = epilogue(A x) over the pattern dictionary.  halo: 0 none; 1 both launches read ghosts from xg (the caller has
@@ -218,6 +650,20 @@ int mxg_pat_build(mxg_csr* a, const int64_t* rp, const int32_t* ci, const double
       const int64_t q0 = rp[r], q1 = rp[r + 1];
       const int len = (int)(q1 - q0);
       if (len == 0 || len > PAT_LEN) continue;
+      // on the Yee lattice a row repeats the pattern of the row three (same component, previous cell of the grid line) or
+      // one before it for hundreds of rows: compare the CSR entries directly and skip the hash for those
+      bool reused = false;
+      for (int back = 3; back >= 1 && !reused; back -= 2) {
+        const int64_t pr = r - back;
+        if (pr < r0 || rowpid[(size_t)pr] == PAT_NONE) continue;
+        const int64_t p0 = rp[pr];
+        if (rp[pr + 1] - p0 != len) continue;
+        bool same = true;
+        for (int i = 0; i < len && same; ++i)
+          same = ((int64_t)ci[q0 + i] - r == (int64_t)ci[p0 + i] - pr) && std::memcmp(&va[q0 + i], &va[p0 + i], 8) == 0;
+        if (same) { rowpid[(size_t)r] = rowpid[(size_t)pr]; reused = true; }
+      }
+      if (reused) continue;
       sg.assign((size_t)len * 12, '\0');
       for (int i = 0; i < len; ++i) {
         const int32_t dl = (int32_t)((int64_t)ci[q0 + i] - r);
@@ -279,5 +725,114 @@ int mxg_pat_build(mxg_csr* a, const int64_t* rp, const int32_t* ci, const double
   int64_t gnnz = 0;
   for (int32_t r : grows) gnnz += rp[r + 1] - rp[r];
   a->pat_gnnz = gnnz;
+  return 0;
+}
+
+// Row-pair dictionary: pairs (2m, 2m+1) of rows with the same length (<= 8) and the same column offsets share a
+// pattern; everything else (and the last row of an odd matrix) goes to the list of individual rows.
+int mxg_pair_build(mxg_csr* a, const int64_t* rp, const int32_t* ci, const double* va) {
+  mxg_ctx* c = a->ctx;
+  const int64_t n = a->nrows, npairs = n / 2;
+  std::vector<unsigned short> pairid((size_t)std::max<int64_t>(npairs, 1), PAT_NONE);
+  std::vector<PairEntry> dict;
+  std::unordered_map<std::string, int> global;
+  std::mutex mu;
+  auto pairable = [&](int64_t m) -> int {          // length of the shared pattern, -1 if the rows do not pair
+    const int64_t r = 2 * m, qa = rp[r], qb = rp[r + 1];
+    const int64_t len = qb - qa;
+    if (rp[r + 2] - qb != len || len > PAT_LEN) return -1;
+    for (int64_t i = 0; i < len; ++i)
+      if ((int64_t)ci[qa + i] - r != (int64_t)ci[qb + i] - (r + 1)) return -1;
+    return (int)len;
+  };
+  auto work = [&](int64_t m_lo, int64_t m_hi) {
+    std::unordered_map<std::string, int> local;
+    std::string sg;
+    for (int64_t m = m_lo; m < m_hi; ++m) {
+      const int len = pairable(m);
+      if (len < 0) continue;
+      const int64_t r = 2 * m, qa = rp[r], qb = rp[r + 1];
+      // the pair three before (same components, previous cells of the grid line) usually has the same pattern
+      bool reused = false;
+      for (int back = 3; back >= 1 && !reused; back -= 2) {
+        const int64_t pm = m - back;
+        if (pm < m_lo || pairid[(size_t)pm] == PAT_NONE) continue;
+        const int64_t pr = 2 * pm, pa = rp[pr], pb = rp[pr + 1];
+        if (pb - pa != len || rp[pr + 2] - pb != len) continue;
+        bool same = true;
+        for (int i = 0; i < len && same; ++i)
+          same = ((int64_t)ci[qa + i] - r == (int64_t)ci[pa + i] - pr) && std::memcmp(&va[qa + i], &va[pa + i], 8) == 0 &&
+                 std::memcmp(&va[qb + i], &va[pb + i], 8) == 0;
+        if (same) { pairid[(size_t)m] = pairid[(size_t)pm]; reused = true; }
+      }
+      if (reused) continue;
+      sg.assign(4 + (size_t)len * 20, '\0');
+      std::memcpy(&sg[0], &len, 4);
+      for (int i = 0; i < len; ++i) {
+        const int32_t dl = (int32_t)((int64_t)ci[qa + i] - r);
+        std::memcpy(&sg[4 + (size_t)i * 20], &dl, 4);
+        std::memcpy(&sg[4 + (size_t)i * 20 + 4], &va[qa + i], 8);
+        std::memcpy(&sg[4 + (size_t)i * 20 + 12], &va[qb + i], 8);
+      }
+      auto it = local.find(sg);
+      int id;
+      if (it != local.end()) {
+        id = it->second;
+      } else {
+        std::lock_guard<std::mutex> lk(mu);
+        auto g = global.find(sg);
+        if (g != global.end()) {
+          id = g->second;
+        } else if (dict.size() < (size_t)PAT_NONE) {
+          PairEntry e{};
+          e.len = len;
+          for (int i = 0; i < len; ++i) {
+            e.delta[i] = (int32_t)((int64_t)ci[qa + i] - r);
+            e.va[i] = va[qa + i];
+            e.vb[i] = va[qb + i];
+          }
+          id = (int)dict.size();
+          dict.push_back(e);
+          global.emplace(sg, id);
+        } else {
+          id = -1;
+        }
+        local.emplace(sg, id);
+      }
+      if (id >= 0) pairid[(size_t)m] = (unsigned short)id;
+    }
+  };
+  unsigned nthreads = std::thread::hardware_concurrency();
+  if (const char* e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) nthreads = (unsigned)v; }
+  if (nthreads > 32) nthreads = 32;
+  if (nthreads < 1 || npairs < 4096) nthreads = 1;
+  std::vector<std::thread> pool;
+  for (unsigned i = 0; i < nthreads; ++i) pool.emplace_back(work, npairs * i / nthreads, npairs * (i + 1) / nthreads);
+  for (auto& th : pool) th.join();
+  std::vector<int32_t> grows;
+  for (int64_t m = 0; m < npairs; ++m)
+    if (pairid[(size_t)m] == PAT_NONE) { grows.push_back((int32_t)(2 * m)); grows.push_back((int32_t)(2 * m + 1)); }
+  if (n & 1) grows.push_back((int32_t)(n - 1));
+  if (a->d_pairid) hipFree(a->d_pairid);
+  if (a->d_pairdict) hipFree(a->d_pairdict);
+  if (a->d_grows) hipFree(a->d_grows);
+  a->d_pairid = nullptr; a->d_pairdict = nullptr; a->d_grows = nullptr;
+  MXG_HIP(hipMalloc(&a->d_pairid, sizeof(unsigned short) * pairid.size()));
+  MXG_HIP(hipMalloc(&a->d_pairdict, sizeof(PairEntry) * std::max<size_t>(dict.size(), 1)));
+  MXG_HIP(hipMalloc(&a->d_grows, sizeof(int32_t) * std::max<size_t>(grows.size(), 1)));
+  MXG_HIP(hipMemcpyAsync(a->d_pairid, pairid.data(), sizeof(unsigned short) * pairid.size(), hipMemcpyHostToDevice, c->stream));
+  if (!dict.empty())
+    MXG_HIP(hipMemcpyAsync(a->d_pairdict, dict.data(), sizeof(PairEntry) * dict.size(), hipMemcpyHostToDevice, c->stream));
+  if (!grows.empty())
+    MXG_HIP(hipMemcpyAsync(a->d_grows, grows.data(), sizeof(int32_t) * grows.size(), hipMemcpyHostToDevice, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  a->pat_npair = (int64_t)dict.size();
+  a->pat_ngrows = (int64_t)grows.size();
+  int64_t gnnz = 0;
+  for (int32_t r : grows) gnnz += rp[r + 1] - rp[r];
+  a->pat_gnnz = gnnz;
+  if (getenv("MXG_PAT_STATS"))
+    fprintf(stderr, "[mxg_pat] %lld rows: %lld pair patterns, %lld individual rows (%.2f %%, %lld entries)\n", (long long)n,
+            (long long)dict.size(), (long long)grows.size(), 100.0 * grows.size() / std::max<int64_t>(n, 1), (long long)gnnz);
   return 0;
 }

@@ -1,0 +1,208 @@
+// Micro-benchmark behind DESIGN.md section 4.1c: what bounds a 7-point stencil product y[r] = sum_l c_l x[r + off_l]
+// on the Yee numbering (offsets 0, +-3, +-3(N+1), +-3(N+1)^2; 20.6 M rows) once the matrix stream is gone?
+//   v0  one thread per row, 7 global gathers                       (what k_spmv_pat does)
+//   v1  the same with all offsets inside the row's own 2 KB window (every gather an L1 hit)
+//   v2  two consecutive rows per thread, 16-byte gathers
+//   v3  x windows of a 256-row block staged in LDS (5 windows), 7 LDS reads per row
+//   v4  x windows of a TJ x TI tile of grid lines staged in LDS: each x entry fetched once per tile
+// Build: hipcc -O3 --offload-arch=gfx950 scripts/ubench_gather.hip -o scripts/bin/ubench_gather
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int NXCD = 8;
+__device__ inline long long xcd_block(long long w, long long nblocks) {
+  const long long per = (nblocks + NXCD - 1) / NXCD;
+  return (w % NXCD) * per + (w / NXCD);
+}
+
+struct Legs { long long off[7]; double c[7]; };
+
+__global__ __launch_bounds__(256) void k_v0(const double* __restrict__ x, double* __restrict__ y, long long n, long long lo,
+                                             long long hi, Legs L, long long nblocks) {
+  const long long b = xcd_block(blockIdx.x, nblocks);
+  if (b >= nblocks) return;
+  const long long r = lo + b * 256 + threadIdx.x;
+  if (r >= hi) return;
+  double xv[7];
+#pragma unroll
+  for (int l = 0; l < 7; ++l) xv[l] = x[r + L.off[l]];
+  double s = 0.0;
+#pragma unroll
+  for (int l = 0; l < 7; ++l) s += L.c[l] * xv[l];
+  __builtin_nontemporal_store(s, y + r);
+}
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(128) void k_v2(const double* __restrict__ x, double* __restrict__ y, long long n, long long lo,
+                                             long long hi, Legs L, long long nblocks) {
+  const long long b = xcd_block(blockIdx.x, nblocks);
+  if (b >= nblocks) return;
+  const long long r = lo + b * 256 + 2 * threadIdx.x;
+  if (r + 1 >= hi) return;
+  dbl2 xv[7];
+#pragma unroll
+  for (int l = 0; l < 7; ++l) {
+    const double* p = x + r + L.off[l];
+    // dword-aligned 16-byte global load (global_load_dwordx4 needs no more)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xv[l]) : "v"(p) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int l = 0; l < 7; ++l) { s0 += L.c[l] * xv[l].x; s1 += L.c[l] * xv[l].y; }
+  dbl2 o; o.x = s0; o.y = s1;
+  __builtin_nontemporal_store(o, reinterpret_cast<dbl2*>(y + r));
+}
+
+// LDS windows of one 256-row block: [r0-3, r0+259) and the four far windows [r0+off, r0+off+256)
+__global__ __launch_bounds__(256) void k_v3(const double* __restrict__ x, double* __restrict__ y, long long n, long long lo,
+                                             long long hi, Legs L, long long nblocks) {
+  __shared__ double w[5][264];
+  const long long b = xcd_block(blockIdx.x, nblocks);
+  if (b >= nblocks) return;
+  const long long r0 = lo + b * 256;
+  const int t = threadIdx.x;
+  // legs: 0: 0, 1: -3, 2: +3, 3/4: -+y, 5/6: -+z
+  w[0][t + 3] = x[r0 + t];
+  if (t < 3) { w[0][t] = x[r0 - 3 + t]; w[0][259 + t] = x[r0 + 256 + t]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[1 + q][t] = x[r0 + L.off[3 + q] + t];
+  __syncthreads();
+  const long long r = r0 + t;
+  if (r >= hi) return;
+  double s = 0.0;
+  s += L.c[0] * w[0][t + 3];
+  s += L.c[1] * w[0][t];
+  s += L.c[2] * w[0][t + 6];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s += L.c[3 + q] * w[1 + q][t];
+  __builtin_nontemporal_store(s, y + r);
+}
+
+// Tile of TJ lines (stride sy) x TI planes (stride sz), SEG rows of each line: self windows + y halo + z halo in LDS.
+// Every x entry of the tile is fetched once; per line 1 + 2/TJ + 2/TI windows instead of 5.
+template <int TJ, int TI, int SEG>
+__global__ __launch_bounds__(256) void k_v4(const double* __restrict__ x, double* __restrict__ y, long long lo, long long sy,
+                                             long long sz, int nseg, int ntj, int nti, Legs L, long long ntiles) {
+  extern __shared__ double lds[];
+  constexpr int WS = SEG + 8;                                   // window stride in LDS (3 halo entries each side, padded)
+  const long long tile = xcd_block(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
+  const int seg = (int)(tile % nseg);
+  const int tj = (int)((tile / nseg) % ntj);
+  const int ti = (int)(tile / ((long long)nseg * ntj));
+  const long long base = lo + (long long)ti * TI * sz + (long long)tj * TJ * sy + (long long)seg * SEG;
+  // window (j, i), j in [-1, TJ], i in [-1, TI] without the four corners; index ((i+1) * (TJ+2) + (j+1))
+  const int t = threadIdx.x;
+  for (int wq = 0; wq < (TJ + 2) * (TI + 2); ++wq) {
+    const int j = wq % (TJ + 2) - 1, i = wq / (TJ + 2) - 1;
+    const bool edge_j = j < 0 || j >= TJ, edge_i = i < 0 || i >= TI;
+    if (edge_j && edge_i) continue;
+    const double* src = x + base + (long long)i * sz + (long long)j * sy - 4;
+    double* dst = lds + (size_t)wq * WS;
+    for (int q = t; q < WS; q += 256) dst[q] = src[q];
+  }
+  __syncthreads();
+  for (int li = 0; li < TI; ++li)
+    for (int lj = 0; lj < TJ; ++lj) {
+      const double* c0 = lds + (size_t)((li + 1) * (TJ + 2) + (lj + 1)) * WS + 4;
+      const double* ym = lds + (size_t)((li + 1) * (TJ + 2) + lj) * WS + 4;
+      const double* yp = lds + (size_t)((li + 1) * (TJ + 2) + (lj + 2)) * WS + 4;
+      const double* zm = lds + (size_t)(li * (TJ + 2) + (lj + 1)) * WS + 4;
+      const double* zp = lds + (size_t)((li + 2) * (TJ + 2) + (lj + 1)) * WS + 4;
+      for (int q = t; q < SEG; q += 256) {
+        double s = 0.0;
+        s += L.c[0] * c0[q];
+        s += L.c[1] * c0[q - 3];
+        s += L.c[2] * c0[q + 3];
+        s += L.c[3] * ym[q];
+        s += L.c[4] * yp[q];
+        s += L.c[5] * zm[q];
+        s += L.c[6] * zp[q];
+        __builtin_nontemporal_store(s, y + base + (long long)li * sz + (long long)lj * sy + q);
+      }
+    }
+}
+
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 189;                 // 3 * 190^3 = 20.6 M rows
+  const long long M = N + 1, sy = 3 * M, sz = 3 * M * M, n = 3 * M * M * M;
+  double *x, *y;
+  CHECK(hipMalloc(&x, sizeof(double) * (n + 4096)));
+  CHECK(hipMalloc(&y, sizeof(double) * (n + 4096)));
+  std::vector<double> hx(n);
+  for (long long i = 0; i < n; ++i) hx[i] = (double)((i * 2654435761u) & 1023) / 1024.0;
+  CHECK(hipMemcpy(x, hx.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  CHECK(hipMemset(y, 0, sizeof(double) * n));
+  Legs far{{0, -3, 3, -sy, sy, -sz, sz}, {6.0, -1.0, -1.0, -1.0, -1.0, -1.0, -1.0}};
+  Legs near{{0, -3, 3, -2, 2, -1, 1}, {6.0, -1.0, -1.0, -1.0, -1.0, -1.0, -1.0}};
+  const long long lo = sz + sy + 256, hi = n - sz - sy - 256;   // interior rows only
+  const long long rows = hi - lo, nb = rows / 256;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  auto run = [&](const char* name, auto launch, double rowsdone) {
+    for (int i = 0; i < 3; ++i) launch();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < 20; ++i) launch();
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+    std::vector<double> hy(4);
+    printf("%-44s %8.4f ms  %6.1f Mrows  %7.1f GB/s of (x + y) bytes  scaled to 20.6 M rows: %.4f ms\n", name, ms, rowsdone / 1e6,
+           rowsdone * 16 / ms / 1e6, ms * 20608881.0 / rowsdone);
+    fflush(stdout);
+  };
+  const unsigned grid = (unsigned)(((nb + NXCD - 1) / NXCD) * NXCD);
+  run("v0 7 global gathers per row", [&] { hipLaunchKernelGGL(k_v0, dim3(grid), dim3(256), 0, 0, x, y, n, lo, hi, far, nb); }, nb * 256.0);
+  run("v1 7 gathers, all in the own window (L1)", [&] { hipLaunchKernelGGL(k_v0, dim3(grid), dim3(256), 0, 0, x, y, n, lo, hi, near, nb); }, nb * 256.0);
+  run("v2 two rows per thread, 16-byte gathers", [&] { hipLaunchKernelGGL(k_v2, dim3(grid), dim3(128), 0, 0, x, y, n, lo, hi, far, nb); }, nb * 256.0);
+  run("v3 5 windows of a 256-row block in LDS", [&] { hipLaunchKernelGGL(k_v3, dim3(grid), dim3(256), 0, 0, x, y, n, lo, hi, far, nb); }, nb * 256.0);
+  // reference check of v3 against v0 on a few rows
+  {
+    std::vector<double> a(1024), b(1024);
+    hipLaunchKernelGGL(k_v0, dim3(grid), dim3(256), 0, 0, x, y, n, lo, hi, far, nb);
+    CHECK(hipMemcpy(a.data(), y + lo + 12345, sizeof(double) * 1024, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_v3, dim3(grid), dim3(256), 0, 0, x, y, n, lo, hi, far, nb);
+    CHECK(hipMemcpy(b.data(), y + lo + 12345, sizeof(double) * 1024, hipMemcpyDeviceToHost));
+    int bad = 0; for (int i = 0; i < 1024; ++i) bad += a[i] != b[i];
+    printf("v3 vs v0 mismatches: %d\n", bad);
+    hipLaunchKernelGGL(k_v2, dim3(grid), dim3(128), 0, 0, x, y, n, lo, hi, far, nb);
+    CHECK(hipMemcpy(b.data(), y + lo + 12345, sizeof(double) * 1024, hipMemcpyDeviceToHost));
+    bad = 0; for (int i = 0; i < 1024; ++i) bad += a[i] != b[i];
+    printf("v2 vs v0 mismatches: %d\n", bad);
+  }
+  auto tiles = [&](auto kern, int TJ, int TI, int SEG, const char* name) {
+    // interior box of lines: j in [1, M-1), i in [1, M-1); each line 3*M rows, SEG-row segments (the last partial one skipped)
+    const int nseg = (int)((3 * M - 16) / SEG), ntj = (int)((M - 2) / TJ), nti = (int)((M - 2) / TI);
+    const long long nt = (long long)nseg * ntj * nti;
+    const long long tlo = sz + sy + 8;
+    const size_t shm = sizeof(double) * (size_t)(TJ + 2) * (TI + 2) * (SEG + 8);
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
+      printf("%s: %zu bytes of LDS refused\n", name, shm); (void)hipGetLastError(); return;
+    }
+    const unsigned g = (unsigned)(((nt + NXCD - 1) / NXCD) * NXCD);
+    run(name, [&] { hipLaunchKernelGGL(kern, dim3(g), dim3(256), shm, 0, x, y, tlo, sy, sz, nseg, ntj, nti, far, nt); },
+        (double)nt * TJ * TI * SEG);
+    if (hipGetLastError() != hipSuccess) { printf("%s: launch failed\n", name); return; }
+    // check against v0 on the first tile's first line
+    std::vector<double> a(SEG), b(SEG);
+    CHECK(hipMemcpy(b.data(), y + tlo, sizeof(double) * SEG, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_v0, dim3(grid), dim3(256), 0, 0, x, y, n, lo, hi, far, nb);
+    CHECK(hipMemcpy(a.data(), y + tlo, sizeof(double) * SEG, hipMemcpyDeviceToHost));
+    int bad = 0; for (int i = 0; i < SEG; ++i) bad += a[i] != b[i];
+    printf("   mismatches against v0 on %d rows: %d\n", SEG, bad);
+  };
+  tiles(k_v4<2, 2, 512>, 2, 2, 512, "v4 tile 2 x 2 lines x 512 rows (LDS 66 KB)");
+  tiles(k_v4<4, 4, 256>, 4, 4, 256, "v4 tile 4 x 4 lines x 256 rows (LDS 76 KB)");
+  tiles(k_v4<4, 2, 256>, 4, 2, 256, "v4 tile 4 x 2 lines x 256 rows (LDS 51 KB)");
+  tiles(k_v4<2, 2, 256>, 2, 2, 256, "v4 tile 2 x 2 lines x 256 rows (LDS 34 KB)");
+  tiles(k_v4<8, 1, 256>, 8, 1, 256, "v4 tile 8 x 1 lines x 256 rows (LDS 63 KB)");
+  return 0;
+}

@@ -340,15 +340,15 @@ def test_config3_cylinder_and_config5_sphere_geometries(ctx, rng):
             assert np.array_equal(Y.to_numpy(), cref.spmv(host, x))
 
 
-CS_MODES = {"pat": ("1", "0"), "cs": ("0", "0"), "csp": ("0", "1")}     # (MXG_PAT, MXG_CSP) at compress time
+CS_MODES = {"pair": ("2", "0"), "pat": ("1", "0"), "cs": ("0", "0"), "csp": ("0", "1")}     # (MXG_PAT, MXG_CSP) at compress time
 
 
 @pytest.mark.parametrize("mode", list(CS_MODES))
 def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, mode, monkeypatch):
     """mxg_csr_compress: 16-bit band codes + 8-bit value-table indices per row block; every operator of
     the pillbox (bulk blocks pack, cut-cell blocks fall back to plain CSR rows), SpMV and SpMM, and the
-    fused SpMV+dot of CG give the same bits as the serial row loop.  Modes: "pat" the pattern-dictionary product
-    (k_spmv_pat + k_spmv_gen), "cs" one record per workgroup (k_spmv_cs, the default), "csp" the persistent record
+    fused SpMV+dot of CG give the same bits as the serial row loop.  Modes: "pair" the row-pair pattern product
+    (k_spmv_pair + k_spmv_gen), "pat" the pattern-dictionary product (k_spmv_patw + k_spmv_gen), "cs" one record per workgroup (k_spmv_cs, the default), "csp" the persistent record
     kernel with a loader wave (k_spmv_csp)."""
     monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0]); monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
     _, o = oracle_pillbox16
