@@ -130,6 +130,81 @@ __global__ __launch_bounds__(256) void k_v4(const double* __restrict__ x, double
     }
 }
 
+// v5: prototype of the pipelined pair product.  Pair ids (2 B per pair of rows) and a pattern dictionary in global memory
+// (PairEntry of mxg_pat.hip), persistent wavefronts that take steps of U x 63 pairs cyclically within their XCD's
+// eighth of the rows; per step: ids of step j+2 and pattern of step j+1 are requested before the gathers of step j.
+struct PairEntry { int delta[8]; double va[8]; double vb[8]; int len, pad[23]; };
+struct PRegs { int dl[8]; double va[8], vb[8]; int len; };
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+__device__ inline void pload(const PairEntry* e, PRegs& R) {
+  const u4 d0 = *reinterpret_cast<const u4*>(e->delta), d1 = *reinterpret_cast<const u4*>(e->delta + 4);
+  R.dl[0] = d0.x; R.dl[1] = d0.y; R.dl[2] = d0.z; R.dl[3] = d0.w; R.dl[4] = d1.x; R.dl[5] = d1.y; R.dl[6] = d1.z; R.dl[7] = d1.w;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const dbl2 a = *reinterpret_cast<const dbl2*>(e->va + i), b = *reinterpret_cast<const dbl2*>(e->vb + i);
+    R.va[i] = a.x; R.va[i + 1] = a.y; R.vb[i] = b.x; R.vb[i + 1] = b.y;
+  }
+  R.len = e->len;
+}
+template <int U, bool PIPE>
+__global__ __launch_bounds__(256) void k_v5(const unsigned short* __restrict__ pairid, const PairEntry* __restrict__ dict,
+                                             const double* __restrict__ x, double* __restrict__ y, long long p_lo,
+                                             long long nsteps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x % NXCD;
+  const long long wx = (long long)(blockIdx.x / NXCD) * 4 + wave, Wx = (long long)(gridDim.x / NXCD) * 4;
+  const long long per = (nsteps + NXCD - 1) / NXCD, s_lo = xcd * per, s_hi = min(nsteps, s_lo + per);
+  const bool live = lane < 63;
+  auto pair_of = [&](long long s, int u) { return p_lo + (s * U + u) * 63 + lane; };
+  long long s = s_lo + wx;
+  unsigned pid1[U], pid2[U];                       // ids of the next step / the one after
+  PRegs R, Rn;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    pid1[u] = (live && s < s_hi) ? pairid[pair_of(s, u)] : 0xFFFFu;
+    pid2[u] = (live && s + Wx < s_hi) ? pairid[pair_of(s + Wx, u)] : 0xFFFFu;
+  }
+  if (pid1[0] != 0xFFFFu) pload(dict + pid1[0], Rn);
+  for (; s < s_hi; s += Wx) {
+    unsigned pid0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { pid0[u] = pid1[u]; pid1[u] = pid2[u]; }
+    R = Rn;
+    if (PIPE) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) pid2[u] = (live && s + 2 * Wx < s_hi) ? pairid[pair_of(s + 2 * Wx, u)] : 0xFFFFu;
+      if (pid1[0] != 0xFFFFu) pload(dict + pid1[0], Rn);          // pattern of the next step, in flight during this one
+    }
+    dbl2 xv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = pid0[u] != 0xFFFFu;
+      const long long r = 2 * pair_of(s, u);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const long long cc = ok ? r + R.dl[i] : 0;
+        const dbl2u t = *reinterpret_cast<const dbl2u*>(x + cc);
+        xv[u][i].x = t.x; xv[u][i].y = t.y;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (pid0[u] != 0xFFFFu) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { sa += R.va[i] * xv[u][i].x; sb += R.vb[i] * xv[u][i].y; }
+        dbl2 o; o.x = sa; o.y = sb;
+        __builtin_nontemporal_store(o, reinterpret_cast<dbl2*>(y + 2 * pair_of(s, u)));
+      }
+    if (!PIPE) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) pid2[u] = (live && s + 2 * Wx < s_hi) ? pairid[pair_of(s + 2 * Wx, u)] : 0xFFFFu;
+      if (pid1[0] != 0xFFFFu) pload(dict + pid1[0], Rn);
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 189;                 // 3 * 190^3 = 20.6 M rows
   const long long M = N + 1, sy = 3 * M, sz = 3 * M * M, n = 3 * M * M * M;
@@ -204,5 +279,41 @@ int main(int argc, char** argv) {
   tiles(k_v4<4, 2, 256>, 4, 2, 256, "v4 tile 4 x 2 lines x 256 rows (LDS 51 KB)");
   tiles(k_v4<2, 2, 256>, 2, 2, 256, "v4 tile 2 x 2 lines x 256 rows (LDS 34 KB)");
   tiles(k_v4<8, 1, 256>, 8, 1, 256, "v4 tile 8 x 1 lines x 256 rows (LDS 63 KB)");
+  // v5
+  {
+    const long long p_lo = (lo + 1) / 2, npairs = (hi - lo) / 2 - 8;
+    std::vector<unsigned short> hp(n / 2 + 4096);
+    for (size_t i = 0; i < hp.size(); ++i) hp[i] = (unsigned short)(i % 3);
+    std::vector<PairEntry> hd(3);
+    for (int k = 0; k < 3; ++k) {
+      PairEntry e{};
+      e.len = 7;
+      for (int i = 0; i < 7; ++i) { e.delta[i] = (int)far.off[i]; e.va[i] = far.c[i]; e.vb[i] = far.c[i]; }
+      hd[k] = e;
+    }
+    unsigned short* dp; PairEntry* dd;
+    CHECK(hipMalloc(&dp, hp.size() * 2)); CHECK(hipMalloc(&dd, sizeof(PairEntry) * 3));
+    CHECK(hipMemcpy(dp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dd, hd.data(), sizeof(PairEntry) * 3, hipMemcpyHostToDevice));
+    auto v5 = [&](auto kern, int U, int wgs_per_cu, const char* name) {
+      const long long nsteps = npairs / (63 * U);
+      const unsigned g = 256 * wgs_per_cu;
+      char buf[128]; snprintf(buf, sizeof buf, "%s, %d WGs/CU", name, wgs_per_cu);
+      run(buf, [&] { hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, dp, dd, x, y, p_lo, nsteps); }, (double)nsteps * 63 * U * 2);
+      std::vector<double> a(512), b(512);
+      CHECK(hipMemcpy(b.data(), y + 2 * p_lo + 126 * 40, sizeof(double) * 512, hipMemcpyDeviceToHost));
+      hipLaunchKernelGGL(k_v0, dim3(grid), dim3(256), 0, 0, x, y, n, lo, hi, far, nb);
+      CHECK(hipMemcpy(a.data(), y + 2 * p_lo + 126 * 40, sizeof(double) * 512, hipMemcpyDeviceToHost));
+      int bad = 0; for (int i = 0; i < 512; ++i) bad += a[i] != b[i];
+      printf("   mismatches against v0 on 512 rows: %d\n", bad);
+    };
+    for (int w : {2, 3, 4}) {
+      v5(k_v5<2, true>, 2, w, "v5 pipelined pair product, U = 2");
+      v5(k_v5<2, false>, 2, w, "v5 the same without the pipeline, U = 2");
+    }
+    for (int w : {2, 3}) v5(k_v5<3, true>, 3, w, "v5 pipelined pair product, U = 3");
+    v5(k_v5<1, true>, 1, 4, "v5 pipelined pair product, U = 1");
+    v5(k_v5<1, true>, 1, 6, "v5 pipelined pair product, U = 1");
+  }
   return 0;
 }
