@@ -534,7 +534,7 @@ __global__ __launch_bounds__(PAT_BLOCK) void k_spmv_gen(
 }
 
 // MXG_PATW=0 selects the one-thread-per-row kernel (k_spmv_pat)
-bool patw_on() { static const bool on = !(getenv("MXG_PATW") && atoi(getenv("MXG_PATW")) == 0); return on; }
+bool patw_on() { const char* e = getenv("MXG_PATW"); return !(e && atoi(e) == 0); }   // read per launch: tests switch it
 // workgroups of the wave-persistent kernel: MXG_PATW_WGS per CU (default 4 = 16 wavefronts per CU), but never so many
 // that a wavefront would own fewer than 8 tiles
 long long patw_wgs(const mxg_ctx* c, const mxg_csr* a) {
@@ -545,8 +545,8 @@ long long patw_wgs(const mxg_ctx* c, const mxg_csr* a) {
   return wgs;
 }
 // pairs per lane of the one-shot pair kernel (MXG_PAIR_U = 2, 3 or 4)
-int pair_u() { static const int u = getenv("MXG_PAIR_U") ? std::min(4, std::max(2, atoi(getenv("MXG_PAIR_U")))) : 2; return u; }
-bool pairw_on() { static const bool on = getenv("MXG_PAIRW") && atoi(getenv("MXG_PAIRW")) != 0; return on; }
+int pair_u() { const char* e = getenv("MXG_PAIR_U"); return e ? std::min(4, std::max(2, atoi(e))) : 2; }
+bool pairw_on() { const char* e = getenv("MXG_PAIRW"); return e && atoi(e) != 0; }
 long long pair_wgs(const mxg_ctx* c, const mxg_csr* a) {
   if (pairw_on()) {          // MXG_PAIRW_WGS workgroups per CU (default 4), at least 8 steps per wavefront
     static const int per_cu = getenv("MXG_PAIRW_WGS") ? std::max(1, atoi(getenv("MXG_PAIRW_WGS"))) : 4;

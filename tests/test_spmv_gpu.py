@@ -340,17 +340,28 @@ def test_config3_cylinder_and_config5_sphere_geometries(ctx, rng):
             assert np.array_equal(Y.to_numpy(), cref.spmv(host, x))
 
 
-CS_MODES = {"pair": ("2", "0"), "pat": ("1", "0"), "cs": ("0", "0"), "csp": ("0", "1")}     # (MXG_PAT, MXG_CSP) at compress time
+# (MXG_PAT, MXG_CSP) at compress time, then launch-time switches of the pattern kernels
+CS_MODES = {"pair": ("2", "0", {}), "pair4": ("2", "0", {"MXG_PAIR_U": "4"}), "pairw": ("2", "0", {"MXG_PAIRW": "1"}),
+            "pat": ("1", "0", {}), "patrow": ("1", "0", {"MXG_PATW": "0"}), "cs": ("0", "0", {}), "csp": ("0", "1", {})}
+
+
+def _cs_env(monkeypatch, mode):
+    monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0]); monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
+    for k in ("MXG_PAIR_U", "MXG_PAIRW", "MXG_PATW"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in CS_MODES[mode][2].items():
+        monkeypatch.setenv(k, v)
 
 
 @pytest.mark.parametrize("mode", list(CS_MODES))
 def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, mode, monkeypatch):
     """mxg_csr_compress: 16-bit band codes + 8-bit value-table indices per row block; every operator of
     the pillbox (bulk blocks pack, cut-cell blocks fall back to plain CSR rows), SpMV and SpMM, and the
-    fused SpMV+dot of CG give the same bits as the serial row loop.  Modes: "pair" the row-pair pattern product
-    (k_spmv_pair + k_spmv_gen), "pat" the pattern-dictionary product (k_spmv_patw + k_spmv_gen), "cs" one record per workgroup (k_spmv_cs, the default), "csp" the persistent record
+    fused SpMV+dot of CG give the same bits as the serial row loop.  Modes: "pair" / "pair4" the row-pair pattern product
+    (k_spmv_pair with 2 / 4 pairs per lane + k_spmv_gen), "pairw" its wave-persistent form, "pat" the pattern-dictionary
+    product (k_spmv_patw + k_spmv_gen), "patrow" one thread per row (k_spmv_pat), "cs" one record per workgroup (k_spmv_cs, the default), "csp" the persistent record
     kernel with a loader wave (k_spmv_csp)."""
-    monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0]); monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
+    _cs_env(monkeypatch, mode)
     _, o = oracle_pillbox16
     packed_any = False
     for name in ("vecLapl", "scaLapl", "curlCurl", "curlE", "divB", "gradPsi", "mRhs"):
@@ -387,7 +398,7 @@ def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, mode, monke
 @pytest.mark.parametrize("mode", list(CS_MODES))
 def test_compressed_stream_fallbacks(ctx, rng, mode, monkeypatch):
     """Blocks with more than 16 column bands or 256 distinct values, empty rows and an over-long row."""
-    monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0]); monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
+    _cs_env(monkeypatch, mode)
     n = 9000
     rows = [rng.choice(n, size=int(c), replace=False) for c in rng.integers(0, 12, size=n)]   # scattered columns
     rows[5] = np.arange(n)[:2600]                        # longer than a block
