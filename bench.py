@@ -90,13 +90,41 @@ def spawn_ranks(args):
                    OMP_NUM_THREADS=str(max(1, min(32, host_threads // n))))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's stdout (the JSON line) is drained by a thread; the main thread watches the children: a rank that dies
+    # (no such device, a failed collective) must not leave the others waiting in a rendezvous for ever
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.5)
+    if failed is not None:
+        log("rank %d exited with code %s: stopping the other ranks" % (failed, procs[failed].returncode))
+        time.sleep(5.0)                       # let the others fail on their own (their messages are more useful)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10)
+    rcs = [p.returncode for p in procs]
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     if any(rcs):
         log("rank exit codes: %s" % rcs)
-    sys.exit(max(abs(rc) for rc in rcs) if any(rcs) else 0)
+    sys.exit((max(abs(rc) for rc in rcs if rc) or 1) if any(rcs) else 0)
 
 
 def cpu_eigen_baseline(n):
