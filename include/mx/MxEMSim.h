@@ -69,6 +69,7 @@ class MxEMSim {
     mComplex = cfg.phaseShifts[0] != 0.0 || cfg.phaseShifts[1] != 0.0 || cfg.phaseShifts[2] != 0.0;
     for (auto const& dl : cfg.dielectrics) if (dl.lossy()) mComplex = true;   // loss tangent, src/MxProblem.cpp:507-508
     if (!cfg.pmls.empty()) mComplex = true;                                   // src/MxProblem.cpp:596-597
+    for (auto const& m : cfg.mus) if (m.lossy()) mComplex = true;              // src/MxProblem.cpp:536-537
     if (mComplex) {
       mAsmC = complexAssembler ? complexAssembler : std::make_shared<mx::YeeAssembler<MxComplex> >(cfg);
       addFields(*mAsmC, comm);

@@ -623,10 +623,10 @@ class MxProblem {
     double diag[3], off[3];
     mxdetail::strFill(getAttr("mu diag", node, "[1.0, 1.0, 1.0]"), diag, 3, 0.0);
     mxdetail::strFill(getAttr("mu off diag", node, "[0.0, 0.0, 0.0]"), off, 3, 0.0);
-    if (atof(getAttr("loss tangent", node, "0.0").c_str()) != 0)
-      throw std::runtime_error("MxProblem: a lossy <Mu> (complex permeability) is outside the accelerated path of this build");
+    const double losstan = atof(getAttr("loss tangent", node, "0.0").c_str());
+    if (losstan != 0) pList.set("is complex", true);                        // :536-537
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.mu[i][j] = 0.0;
-    for (int i = 0; i < 3; ++i) m.mu[i][i] = diag[i];
+    for (int i = 0; i < 3; ++i) { m.mu[i][i] = diag[i]; m.muIm[i][i] = diag[i] * losstan; }   // :545-547
     m.mu[0][1] = m.mu[1][0] = off[2];                                        // :549-551
     m.mu[0][2] = m.mu[2][0] = off[1];
     m.mu[1][2] = m.mu[2][1] = off[0];

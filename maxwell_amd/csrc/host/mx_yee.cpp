@@ -41,6 +41,7 @@ YeeAssembler<S>::YeeAssembler(const YeeConfig& cfg) : cfg_(cfg) {
     if (cfg.phaseShifts[i] != 0.0) complexProblem_ = true;
   }
   for (const YeeDielectric& dl : cfg.dielectrics) if (dl.lossy()) lossy_ = true;
+  for (const YeeMu& m : cfg.mus) if (m.lossy()) { muLossy_ = true; complexProblem_ = true; }
   for (const YeePml& pm : cfg.pmls) {                             // MxPML::setProfileEndpoints, src/MxPML.h:107-115
     if (!pm.shape) throw std::runtime_error("YeeAssembler: PML '" + pm.name + "' has no shape");
     PmlGeom g;
@@ -680,7 +681,7 @@ void YeeAssembler<S>::muTupleUpdateC(const int comps[3], const int cells[3][3], 
       asum[c] += af[c];
     }
     Cx mu[3][3];
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) mu[a][b] = Cx(cfg_.mus[i].mu[a][b], 0.0);
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) mu[a][b] = Cx(cfg_.mus[i].mu[a][b], cfg_.mus[i].muIm[a][b]);
     gammaPiC(mu, n, gamma, pi);
     for (int j = 0; j < 3; ++j)
       for (int k = 0; k < 3; ++k) {
@@ -992,14 +993,14 @@ Csr<S> YeeAssembler<S>::muOp() const {
     winCell(B_.wcell[r], ucell);
     canon(ucell, cell);
     bool inMu = false, muDiag = false;
-    double muHere = 1.0;
+    Cx muHere(1.0, 0.0);
     for (size_t i = 0; i < nm; ++i) {                                         // :333-358
       const double l0 = muFracAt(H_, i, comp0, cell), a0 = muFracAt(B_, i, comp0, cell);
       const double (*m)[3] = cfg_.mus[i].mu;
       if (l0 == 1 && a0 == 1) {
         inMu = true;
         muDiag = !(std::abs(m[0][1]) > 0.0 || std::abs(m[0][2]) > 0.0 || std::abs(m[1][2]) > 0.0);   // checkIsDiag, dEps = 0
-        muHere = m[comp0][comp0];
+        muHere = Cx(m[comp0][comp0], cfg_.mus[i].muIm[comp0][comp0]);
         break;
       } else if (l0 == 0 && a0 == 0) {
         continue;
@@ -1008,7 +1009,7 @@ Csr<S> YeeAssembler<S>::muOp() const {
         break;
       }
     }
-    if (!inMu) { muDiag = true; muHere = 1.0; }
+    if (!inMu) { muDiag = true; muHere = Cx(1.0, 0.0); }
     int32_t* rc = cols.data() + r * 9;
     S* rv = vals.data() + r * 9;
     const bool pml = hasPml();
@@ -1019,10 +1020,11 @@ Csr<S> YeeAssembler<S>::muOp() const {
       compCoord(H_, comp0, cell, pc);
       pmlDiag = pmlTransform(pc, false, tr, det);
     }
+    const bool cplxMat = pml || muLossy_;
     if (muDiag && pmlDiag) {                                                  // :413-424
       const std::complex<double> fac = factor(B_, comp0, cell);
       rc[0] = (int32_t)r;
-      Cx v = fac * muHere;
+      Cx v = muLossy_ ? cmul(fac, muHere) : fac * muHere.real();
       if (pml) v = cmul(v, cdiv(cmul(tr[comp0][comp0], tr[comp0][comp0]), det));
       rv[0] = toScalar(v);
       cnt[r] = 1;
@@ -1057,10 +1059,10 @@ Csr<S> YeeAssembler<S>::muOp() const {
       const int* t = tupleInds[use[u]];
       int tcomps[3], tcells[3][3];
       for (int j = 0; j < 3; ++j) { tcomps[j] = scomps[t[j]]; for (int a = 0; a < 3; ++a) tcells[j][a] = scells[t[j]][a]; }
-      if (pml) {
+      if (cplxMat) {
         Cx m[3][3];
         muTupleUpdateC(tcomps, tcells, normal, m);
-        pmlSandwich(tr, det, m);                                              // :434
+        if (pml) pmlSandwich(tr, det, m);                                     // :434
         for (int j = 0; j < 3; ++j) svalsC[t[j]] = svalsC[t[j]] + m[comp0][scomps[t[j]]] / ntd;
       } else {
         double m[3][3];
@@ -1076,7 +1078,7 @@ Csr<S> YeeAssembler<S>::muOp() const {
       const int32_t lid = lidOf(B_, scomps[s], ic);
       if (lid < 0) continue;
       rc[n] = lid;
-      rv[n] = pml ? toScalar(cmul(svalsC[s], fac)) : S(svals[s]) * toScalar(fac);
+      rv[n] = cplxMat ? toScalar(cmul(svalsC[s], fac)) : S(svals[s]) * toScalar(fac);
       ++n;
     }
     for (int x = 1; x < n; ++x) {   // sort by column, merge repeated columns in insertion order (Epetra FillComplete)
@@ -1116,22 +1118,26 @@ Csr<S> YeeAssembler<S>::invMuVolAve() const {
     winCell(P_.wcell[r], ucell);
     canon(ucell, cell);
     double out = 0.0, sums = 0.0;
+    Cx acc(0.0, 0.0);
     for (size_t i = 0; i < cfg_.mus.size(); ++i) {
       const double fr = muFracAt(P_, i, 0, cell);
       const double (*m)[3] = cfg_.mus[i].mu;
+      const double (*mi)[3] = cfg_.mus[i].muIm;
       sums = sums + fr;
-      out = out + fr * (3.0 / (m[0][0] + m[1][1] + m[2][2]));
+      if (muLossy_) acc = acc + cmul(Cx(fr, 0.0), cdiv(Cx(3.0, 0.0), Cx(m[0][0], mi[0][0]) + Cx(m[1][1], mi[1][1]) + Cx(m[2][2], mi[2][2])));
+      else out = out + fr * (3.0 / (m[0][0] + m[1][1] + m[2][2]));
     }
-    out = out + (1.0 - sums) * (3.0 / 3.0);
+    if (muLossy_) acc = acc + Cx((1.0 - sums) * (3.0 / 3.0), 0.0);
+    else { out = out + (1.0 - sums) * (3.0 / 3.0); acc = Cx(out, 0.0); }
     if (hasPml()) {                                       // the layer's 'volume', :765-777: det of the getInvS product
       double pc[3];
       Cx tr[3][3], det;
       compCoord(P_, 0, cell, pc);
       pmlTransform(pc, true, tr, det);
-      d[r] = toScalar(cmul(Cx(out, 0.0), det));
+      d[r] = toScalar(cmul(acc, det));
       continue;
     }
-    d[r] = S(out);
+    d[r] = muLossy_ ? toScalar(acc) : S(out);
   }
   return diagonal<S>(d);
 }

@@ -51,6 +51,11 @@ struct YeeMu {
   std::string name;
   std::shared_ptr<const Shape> shape;
   double mu[3][3];
+  double muIm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // loss tangent t: mu_ii (1 + i t), src/MxProblem.cpp:536-547
+  bool lossy() const {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (muIm[i][j] != 0.0) return true;
+    return false;
+  }
 };
 
 // <PML> block (src/MxProblem.cpp:559-598, src/MxPML.h): stretch s = 1 + i alphaMax ((x - begin) . dir / width)^exponent
@@ -238,6 +243,7 @@ class YeeAssembler {
   struct PmlGeom { double width, dir[3]; std::complex<double> outer[3][3], compl_[3][3]; };
   std::vector<PmlGeom> pmlGeom_;
   bool lossy_ = false;   // complex material arithmetic: a loss tangent or a PML
+  bool muLossy_ = false; // complex permeability
   void setMap(YeeField& F);
   struct Entry { int comp; int off[3]; double val; };
   Csr<S> assemble(const YeeField& rowF, const YeeField& colF, bool skipDeadRows,

@@ -182,7 +182,13 @@ class Deck:
                 name = get_attr("name", child, "mu%d" % len(self.mus))
                 diag = vec(get_attr("mu diag", child, "[1.0, 1.0, 1.0]"))
                 off = vec(get_attr("mu off diag", child, "[0.0, 0.0, 0.0]"))
+                tan = float(get_attr("loss tangent", child, "0.0"))
                 mu = np.diag(diag)
+                if tan != 0:                                     # :536-547
+                    mu = mu.astype(complex) * complex(1.0, 0.0)
+                    for i in range(3):
+                        mu[i, i] = complex(diag[i], diag[i] * tan)
+                    self.params["is complex"] = True
                 mu[0, 1] = mu[1, 0] = off[2]
                 mu[0, 2] = mu[2, 0] = off[1]
                 mu[1, 2] = mu[2, 1] = off[0]

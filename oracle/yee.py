@@ -135,7 +135,14 @@ class YeeSim:
         # magnetic materials: (shape, 3x3 real symmetric mu, name), src/MxProblem.cpp:515-556 / MxMu.cpp.  H lives where B
         # lives (MxYeeMagFieldBase) but is represented by the dual edge through the face centre (src/MxYeeFitHField.cpp:37-47);
         # only built with mu objects (src/MxEMSim.cpp:95-100)
-        self.mus = [(sh, np.array(mu, dtype=float).reshape(3, 3), name) for sh, mu, name in mus]
+        self.mus = []
+        for sh, mu, name in mus:
+            m = np.array(mu).reshape(3, 3)
+            # a loss tangent makes the diagonal complex, mu_ii (1 + i t) (src/MxProblem.cpp:536-549): keep floats otherwise
+            m = m.astype(complex) if np.iscomplexobj(m) and np.any(m.imag != 0.0) else m.real.astype(float)
+            self.mus.append((sh, m, name))
+        self.mu_lossy = any(np.iscomplexobj(m) for _, m, _ in self.mus)
+        self.is_complex = self.is_complex or self.mu_lossy
         H = _Field("hfield", 3, B.coords.copy(), [0, 1, 2]) if (self.mus or self.pmls) else None
         self.H = H
         for F, normal_pec, tang_pec in ((B, ZERO, CONSTANT), (E, CONSTANT, ZERO)) + (((D, CONSTANT, ZERO),) if D else ()) + \
@@ -816,7 +823,7 @@ class YeeSim:
                 tr, det, pml_diag = self._pml_transform(self.comp_coord(H, comp0, cell), False)
             if mu_diag and pml_diag:                                    # :413-424
                 fac = self.factor(B, comp0, cell[None, :])[0]
-                v = complex(fac) * float(mu_here[comp0, comp0])
+                v = complex(fac) * (complex(mu_here[comp0, comp0]) if self.mu_lossy else float(mu_here[comp0, comp0].real))
                 if self.pmls:
                     v = v * self._cdiv(tr[comp0][comp0] * tr[comp0][comp0], det)
                 rows.append(r); cols.append(r); vals.append(v)
@@ -844,7 +851,7 @@ class YeeSim:
             nt = float(len(tuples))
             for t in tuples:                                            # :427-440
                 tc, tl = [scomps[si] for si in t], [scells[si] for si in t]
-                m = self._mu_tuple_update_c(tc, tl, normal) if self.pmls else self._mu_tuple_update(tc, tl, normal)
+                m = self._mu_tuple_update_c(tc, tl, normal) if (self.pmls or self.mu_lossy) else self._mu_tuple_update(tc, tl, normal)
                 if self.pmls:                                           # :434
                     m = self._pml_sandwich(tr, det, m)
                 for si in t:
@@ -895,11 +902,22 @@ class YeeSim:
         """cellAveInvMuOperator, src/MxYeeFitMu.cpp:532-600: volume-fraction average of 3/trace(mu) on the Psi map."""
         P = self.P
         out = np.zeros(len(P.gids)); sums = np.zeros(len(P.gids))
-        for sh, mu, nm in self.mus:
+        for sh, mu, nm in ([] if self.mu_lossy else self.mus):
             fr = self.frac_at(P, 0, P.cells, nm)
             sums = sums + fr
             out = out + fr * (3.0 / (mu[0, 0] + mu[1, 1] + mu[2, 2]))
         out = out + (1.0 - sums) * (3.0 / 3.0)
+        if self.mu_lossy:        # complex permeability: scalar loop with the explicit quotient, as inv_eps_vol_ave
+            fracs = [self.frac_at(P, 0, P.cells, nm) for _, _, nm in self.mus]
+            scal = [self._cdiv(complex(3.0, 0.0), complex(mu[0, 0]) + complex(mu[1, 1]) + complex(mu[2, 2])) for _, mu, _ in self.mus]
+            out = np.zeros(len(P.gids), dtype=complex)
+            for r in range(len(P.gids)):
+                acc, sm = 0j, 0.0
+                for fr, sc in zip(fracs, scal):
+                    f = float(fr[r])
+                    sm = sm + f
+                    acc = acc + complex(f, 0.0) * sc
+                out[r] = acc + complex((1.0 - sm) * (3.0 / 3.0), 0.0)
         if self.is_complex:
             out = out.astype(complex)
         if self.pmls:                                          # the layer's 'volume', :765-777: det of the getInvS product

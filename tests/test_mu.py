@@ -32,6 +32,16 @@ def test_uniform_permeability_scales_the_spectrum():
     assert np.allclose(w0 / w1, 2.5, rtol=1e-10)
 
 
+def test_uniform_lossy_permeability_scales_the_spectrum_by_a_complex_factor():
+    """mu_r (1 + i t) everywhere: every k^2 divided by exactly that number (damped modes, Q = 1 / t)."""
+    kw = dict(origin=(0, 0, 0), size=(1.0, 0.8, 0.6), lower=("pec",) * 3, upper=("pec",) * 3)
+    w0 = yee.mag_wave_modes(yee.YeeSim([6, 6, 6], **kw).wave_ops(), 1.0, 4)
+    everywhere = geo.Sphere(10.0, [0, 0, 0])
+    mu = 2.5 * (1.0 + 0.05j)
+    w1 = yee.mag_wave_modes(yee.YeeSim([6, 6, 6], mus=[(everywhere, mu * np.eye(3), "m")], **kw).wave_ops(), 1.0, 4)
+    assert np.iscomplexobj(w1) and np.allclose(np.sort_complex(w0 / w1), mu, rtol=1e-10)
+
+
 @pytest.mark.parametrize("normal", [(0, 0, 1), (1, 1, 0), (1, 2, 3), (-2, 1, 0.5)])
 @pytest.mark.parametrize("kind", ["iso", "aniso"])
 def test_mu_stencil_is_exact_on_a_tilted_planar_interface(normal, kind):

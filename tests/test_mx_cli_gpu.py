@@ -207,6 +207,22 @@ def test_magnetic_sphere_deck(ctx):
     assert k2[0] < 0.6 * (2.743707269992265 / 0.49) ** 2 and k2[1] - k2[0] > 0.5 and k2[2] - k2[1] > 0.5
 
 
+def test_lossy_magnetic_sphere_deck(ctx):
+    """tests/golden/magsph.mx with `loss tangent = 0.02` on the <Mu> block: complex permeability, complex non-Hermitian
+    Krylov-Schur in the Euclidean inner product; damped modes against the oracle's dense restatement."""
+    text = open(os.path.join(GOLDEN, "magsph.mx")).read().replace(
+        "mu off diag = [0.1, -0.2, 0.3]", "mu off diag = [0.1, -0.2, 0.3]\n    loss tangent = 0.02").replace(
+        "resolution = [10, 10, 10]", "resolution = [8, 8, 8]")
+    deck = mxdeck.Deck(text)
+    assert deck.params["is complex"]
+    solver = mx.Problem(text=text).solver(ctx)
+    assert solver.solve() == 3
+    got = np.array(sorted((solver.result(i)["k2"] for i in range(3)), key=lambda z: z.real))
+    want = yee.mag_wave_modes(deck.sim().wave_ops(), deck.params["eigensolver : shift"], 3)
+    assert np.iscomplexobj(want) and np.all(want.imag < 0)
+    assert np.abs(got - want).max() / np.abs(want).max() < 50 * deck.params["eigensolver : tol"], (got, want)
+
+
 def test_pml_decks_complex_frequencies(ctx):
     """<PML> through MxProblem -> complex MxSolver (src/MxProblem.cpp:596-597 sets "is complex").
     (a) a constant stretch over the whole box (tests/test_pml.py UNIFORM): the exact complex spectrum of the stretched

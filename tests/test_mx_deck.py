@@ -79,7 +79,6 @@ def test_body_line_wins_over_tag_attribute():
      "Invalid lower boundary condition"),
     ("<S>\n polarization = TE\n <Dielectric>\n </Dielectric>\n</S>", "Dielectric"),
     ("<S>\n polarization = TE\n <Mu>\n </Mu>\n</S>", "Mu object"),
-    ("<S>\n polarization = TE\n <Mu>\n loss tangent = 0.1\n <Sphere>\n name = a\n </Sphere>\n </Mu>\n</S>", "lossy <Mu>"),
     ("<S>\n polarization = TE\n <PML>\n </PML>\n</S>", "PML object"),
     ("<S>\n polarization = TE\n <PEC>\n <Torus>\n name = t\n </Torus>\n </PEC>\n</S>", "major radius"),
     ("<S>\n polarization = TE\n <PEC>\n <ShapeSubtract>\n <Sphere>\n name = a\n </Sphere>\n </ShapeSubtract>\n </PEC>\n</S>",
@@ -200,6 +199,15 @@ def test_loss_tangent_makes_the_problem_complex():
     deck, prob = _complex_ops_same(text)
     ie = prob.op("invEps")
     assert np.abs(ie.data.imag).max() > 1e-5
+
+
+def test_lossy_mu_makes_the_problem_complex():
+    """<Mu> `loss tangent` t: mu_ii (1 + i t) (src/MxProblem.cpp:536-547) - complex FIT permeability (diagonal path and
+    the 9-point tuple stencil in complex arithmetic), complex invMuVolAve, complex chain; bit-identical to the oracle."""
+    text = _text("magsph.mx").replace("mu off diag = [0.1, -0.2, 0.3]", "mu off diag = [0.1, -0.2, 0.3]\n    loss tangent = 0.02")
+    text = text.replace("resolution = [10, 10, 10]", "resolution = [8, 8, 8]")
+    deck, prob = _complex_ops_same(text)
+    assert np.abs(prob.op("mu").data.imag).max() > 1e-3 and np.abs(prob.op("invMuVolAve").data.imag).max() > 1e-4
 
 
 def test_complex_inverse_permittivity_with_bloch_phases():
