@@ -128,6 +128,10 @@ int mxg_csr_set_kernel(mxg_csr* a, int which);
  * headline SpMV measurement of bench.py stays on the plain CSR arrays. */
 int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes);
 /* same, encoding from the caller's host copy of the CSR arrays given to mxg_csr_create (saves reading them back) */
+/* Which product kernel a compressed matrix runs: returns 0 plain CSR, 1 compressed stream (k_spmv_cs), 3 tile patterns
+ * (k_spmv_tile: lattice operators whose rows repeat along grid lines; MXG_PAT=0 at compress time keeps form 1).
+ * tiles / patterns / irregular_rows / coverage (fraction of the rows inside tiles) describe form 3; any may be NULL. */
+int mxg_csr_product_form(const mxg_csr* a, int64_t* tiles, int64_t* patterns, int64_t* irregular_rows, double* coverage);
 int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals,
                           int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes);
 

@@ -93,6 +93,7 @@ MXG_SIGNATURES = {
     "mxg_mv_times_mat": (C.c_int, [C.c_double, C.c_double, vp, vp, C.c_int, C.c_int, C.c_int,
                                    C.c_double, C.c_double, vp]),
     "mxg_mv_trans_mv": (C.c_int, [C.c_double, C.c_double, vp, vp, vp, C.c_int]),
+    "mxg_csr_product_form": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "mxg_mv_trans_mv2": (C.c_int, [C.c_double, C.c_double, vp, vp, vp, vp, C.c_int]),
     "mxg_mg_create": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
                                 C.c_double, C.c_double, C.POINTER(vp)]),

@@ -342,6 +342,12 @@ class CsrMatrix:
         _chk(self.lib.mxg_csr_compress(self.h, C.byref(nb), C.byref(nf), C.byref(sb)), self.lib)
         return nb.value, nf.value, sb.value
 
+    def product_form(self):
+        """(form, tiles, tile patterns, irregular rows, coverage): form 0 plain CSR, 1 compressed stream, 3 tile patterns."""
+        t, p, g, cov = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
+        form = self.lib.mxg_csr_product_form(self.h, C.byref(t), C.byref(p), C.byref(g), C.byref(cov))
+        return form, t.value, p.value, g.value, cov.value
+
     def solve(self, b, x, method="cg", tol=1e-6, restart=40, max_iters=0, precond="none", mg=None):
         opts = _lib.SolveOpts(tol, restart, max_iters, {"none": 0, "jacobi": 1, "mg": 3}[precond], 0, 0.0, 0.0,
                               mg.handle if mg is not None else None)

@@ -1587,6 +1587,8 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (a->d_patdict) hipFree(a->d_patdict);
   if (a->d_grows) hipFree(a->d_grows);
   if (a->d_pairid) hipFree(a->d_pairid);
+  if (a->d_tiledesc) hipFree(a->d_tiledesc);
+  if (a->d_tiledict) hipFree(a->d_tiledict);
   if (a->d_pairdict) hipFree(a->d_pairdict);
   if (a->d_csdesc) hipFree(a->d_csdesc);
   if (a->d_csstream) hipFree(a->d_csstream);
@@ -1812,9 +1814,23 @@ static bool csp_wanted() { const char* e = getenv("MXG_CSP"); return e && atoi(e
 // MXG_PAT=1: the pattern-dictionary product (mxg_pat.hip).  Opt-in: at 256^3 the scalar Laplacian runs 0.051 ms
 // against 0.068 ms, the vector Laplacian 0.225 against 0.202 (its individual wall rows), the eigen-solve 2.63 s against
 // 2.44 s - every variant lands near 0.2 ms: the 7 gathers per row, not the matrix bytes, set the time.
-static int pat_mode() { const char* e = getenv("MXG_PAT"); return e ? atoi(e) : 0; }   // 1: row patterns, 2: row pairs
+// Product kernel of compressed matrices: 3 (default) wavefront-uniform tile patterns where they cover the matrix
+// (lattice operators; k_spmv_tile), otherwise and with 0 the compressed stream (k_spmv_cs); 1 row patterns, 2 row pairs
+// (mxg_pat.hip; experiments kept for the record, profiles/r02e)
+extern "C" int mxg_csr_product_form(const mxg_csr* a, int64_t* tiles, int64_t* patterns, int64_t* irregular_rows, double* coverage) {
+  if (!a) return -1;
+  const bool tile = (a->kernel & 0x10000000) != 0 && a->d_tiledesc != nullptr;
+  if (tiles) *tiles = tile ? a->pat_ntile : 0;
+  if (patterns) *patterns = tile ? a->pat_ntilepat : 0;
+  if (irregular_rows) *irregular_rows = tile ? a->pat_ngrows : 0;
+  if (coverage) *coverage = a->pat_tile_coverage;
+  if (tile) return 3;
+  return (a->kernel & 0x1000000) != 0 && a->ncs > 0 ? 1 : 0;
+}
+
+static int pat_mode() { const char* e = getenv("MXG_PAT"); return e ? atoi(e) : 3; }
 static bool pat_wanted() { return pat_mode() != 0; }
-static inline bool pat_on(const mxg_csr* a) { return (a->kernel & 0x10000000) != 0 && (a->d_rowpid != nullptr || a->d_pairid != nullptr); }
+static inline bool pat_on(const mxg_csr* a) { return (a->kernel & 0x10000000) != 0 && (a->d_rowpid != nullptr || a->d_pairid != nullptr || a->d_tiledesc != nullptr); }
 
 // Records for the compressed-stream kernels over the row blocks of the row-gather geometry (RgCfgA).
 //   [header 32 B][pattern table + per-row pattern ids: patterned records only]
@@ -2077,12 +2093,13 @@ extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const in
     MXG_TRY(build_cs(a, rowptr, colidx, vals, want_csp));
     a->cs_patterned = (int)want_csp;
     // the pattern-dictionary product (mxg_pat.hip) for matrices without ghosts; MXG_PAT=0 keeps the record kernels
-    if (pat_mode() == 2 && a->nghost == 0 && a->nneigh == 0 && !a->d_pairid) MXG_TRY(mxg_pair_build(a, rowptr, colidx, vals));
-    else if (pat_wanted() && a->nghost == 0 && a->nneigh == 0 && !a->d_rowpid && !a->d_pairid) MXG_TRY(mxg_pat_build(a, rowptr, colidx, vals));
+    if (pat_mode() == 3 && a->nghost == 0 && a->nneigh == 0 && !a->d_tiledesc) MXG_TRY(mxg_tile_build(a, rowptr, colidx, vals));
+    else if (pat_mode() == 2 && a->nghost == 0 && a->nneigh == 0 && !a->d_pairid) MXG_TRY(mxg_pair_build(a, rowptr, colidx, vals));
+    else if (pat_mode() == 1 && a->nghost == 0 && a->nneigh == 0 && !a->d_rowpid) MXG_TRY(mxg_pat_build(a, rowptr, colidx, vals));
   }
   // 0x8000000: the persistent kernel with a loader wave over patterned records (k_spmv_csp); MXG_CSP=0 at compress
   // time builds the plain records and keeps one block per workgroup (k_spmv_cs)
-  a->kernel = MXG_KERNEL_DEFAULT | 0x1000000 | (want_csp ? 0x8000000 : 0) | ((pat_wanted() && (a->d_rowpid || a->d_pairid)) ? 0x10000000 : 0);
+  a->kernel = MXG_KERNEL_DEFAULT | 0x1000000 | (want_csp ? 0x8000000 : 0) | ((pat_wanted() && (a->d_rowpid || a->d_pairid || a->d_tiledesc)) ? 0x10000000 : 0);
   if (nblocks) *nblocks = a->ncs;
   if (nfallback) *nfallback = a->cs_fallback;
   if (stream_bytes) *stream_bytes = a->cs_bytes;

@@ -147,6 +147,10 @@ struct mxg_csr {
   unsigned short* d_pairid = nullptr;   // row-pair form of the pattern product (mxg_pat.hip): id per pair of rows
   void* d_pairdict = nullptr;
   int64_t pat_npair = 0;
+  void* d_tiledesc = nullptr;           // tile form of the pattern product (mxg_pat.hip, MXG_PAT=3): 16-byte tile descriptors,
+  void* d_tiledict = nullptr;           // wavefront-uniform tile patterns; irregular rows in d_grows
+  int64_t pat_ntile = 0, pat_ntilepat = 0;
+  double pat_tile_coverage = 0.0;       // fraction of the rows inside tiles
   int64_t cs_pattern_rows = 0;   // rows encoded as one pattern id (persistent kernel's records)
   int64_t ncs_interior = 0;      // compressed descriptors [0, ncs_interior) reference no ghost column
   // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
@@ -201,6 +205,7 @@ int mxg_dev_csr_apply_dot(mxg_ctx* ctx, mxg_csr* a, const mxg_mv* x, mxg_mv* y, 
 // pattern-dictionary product (mxg_pat.hip)
 int mxg_pat_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
 int mxg_pair_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
+int mxg_tile_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
 int64_t mxg_pat_partials(const mxg_csr* a);
 int mxg_pat_launch(mxg_ctx* c, mxg_csr* a, const double* x, double* y, int epi, int dot, const double* xdot,
                    double* partial, const double* rhs, const double* diag, double omega, double beta, int halo,

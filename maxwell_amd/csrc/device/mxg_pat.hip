@@ -494,6 +494,142 @@ __global__ __launch_bounds__(64 * PAIR_WAVES) void k_spmv_pairw(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile form ("tile", MXG_PAT=3): patterns that are uniform per wavefront, fetched through SCALAR loads.
+// A run is a stretch of consecutive rows that all have the same length and column offsets and in which every row
+// repeats the values of the row three before it (same component, next cell of the grid line) - the interior of a grid
+// line.  Runs are cut into tiles of <= 126 rows (63 lanes x 2 rows; a multiple of three, so every tile of a run has
+// the same pattern): 16 bytes of descriptor {first row, rows, pattern} per tile, and a pattern = {length, offsets,
+// values of row offsets 0, 1, 2 mod 3}.  A wavefront reads descriptor and pattern with s_load, so the gather addresses
+// are SGPR base + lane * 16 with no vector arithmetic and no per-lane dependent load in front of them, two rows per
+// lane share each 16-byte gather, and a lane picks its two value lists by (2 lane) mod 3 with v_cndmask.  This is the
+// form of scripts/ubench_gather.hip's v2 kernel (0.054 ms for 20.6 M rows).  Rows outside tiles (the cavity wall, line
+// ends, runs shorter than TILE_MIN_RUN) are walked over the CSR arrays by the first workgroups of the SAME launch.
+struct TileDesc { int start, nrows, pid, pad; };                     // 16 bytes
+struct TileEntry {                                                   // 256 bytes
+  int len, pad0[7];
+  int delta[PAT_LEN];
+  double v[3][PAT_LEN];
+};
+static_assert(sizeof(TileEntry) == 256, "tile dictionary entry layout");
+constexpr int TILE_ROWS = 126, TILE_WAVES = 4, TILE_MIN_RUN = 24, TILE_TPW = 2;
+
+template <bool DOT, int EPI>
+__global__ __launch_bounds__(64 * TILE_WAVES) void k_spmv_tile(
+    const TileDesc* __restrict__ desc, const TileEntry* __restrict__ dict, long long ntiles, long long ntb, long long ngb,
+    const int* __restrict__ grows, long long ngrows, const long long* __restrict__ rowptr, const int* __restrict__ colidx,
+    const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ xdot,
+    double* __restrict__ partial, const double* __restrict__ rhs, const double* __restrict__ diag, double omega, double beta,
+    bool skipgen) {
+  double part = 0.0;
+  const long long pb = blockIdx.x;                                   // partial slot
+  // The first ngb8 workgroups walk the irregular rows (measured: better than spreading them among the tile groups,
+  // 0.143 against 0.173 ms - while they are resident they take wave slots from the streaming tiles either way)
+  const long long ngb8 = ((ngb + 7) / 8) * 8;
+  const bool gen_group = (long long)blockIdx.x < ngb8;
+  if (gen_group) {
+    // ---- irregular rows: one thread per row over the CSR arrays
+    const long long i = (long long)blockIdx.x * (64 * TILE_WAVES) + threadIdx.x;
+    if (i < ngrows && !skipgen) {
+      const long long row = grows[i];
+      const long long q0 = rowptr[row], q1 = rowptr[row + 1];
+      double sum = 0.0;
+      for (long long q = q0; q < q1; q += 8) {
+        double vv[8], xx[8];
+        int cc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const long long qq = q + j < q1 ? q + j : q1 - 1;
+          cc[j] = colidx[qq];
+          vv[j] = vals[qq];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xx[j] = x[cc[j]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const double s2 = sum + vv[j] * xx[j];
+          sum = q + j < q1 ? s2 : sum;
+        }
+      }
+      y[row] = pat_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y);
+      if (DOT) part = sum * xdot[row];
+    }
+  } else {
+    const long long tb = pat_xcd_block((long long)blockIdx.x - ngb8, ntb);   // XCD w % 8 walks a contiguous eighth of the tiles
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long long t0 = (tb * TILE_WAVES + wave) * TILE_TPW;       // TILE_TPW consecutive tiles per wavefront
+    if (tb < ntb && t0 < ntiles) {
+      const int ca = (2 * lane) % 3, cb = (2 * lane + 1) % 3;
+      TileDesc d[TILE_TPW];
+      const TileEntry* __restrict__ e[TILE_TPW];
+      int len[TILE_TPW];
+      bool on[TILE_TPW];
+#pragma unroll
+      for (int u = 0; u < TILE_TPW; ++u) {                          // wave-uniform: scalar loads
+        const long long t = min(t0 + u, ntiles - 1);
+        d[u] = desc[t];
+        e[u] = dict + d[u].pid;
+        len[u] = e[u]->len;
+        on[u] = t0 + u < ntiles && 2 * lane < d[u].nrows;           // nrows is even
+      }
+      dbl2p xv[TILE_TPW][PAT_LEN];
+#pragma unroll
+      for (int u = 0; u < TILE_TPW; ++u)
+        if (on[u]) {
+#pragma unroll
+          for (int i = 0; i < PAT_LEN; ++i)
+            if (i < len[u]) {                                       // uniform
+              const double* xp = x + ((long long)d[u].start + e[u]->delta[i]);   // scalar base
+              const dbl2u tt = *reinterpret_cast<const dbl2u*>(xp + 2 * lane);
+              xv[u][i].x = tt.x; xv[u][i].y = tt.y;
+            }
+        }
+#pragma unroll
+      for (int u = 0; u < TILE_TPW; ++u)
+        if (on[u]) {
+          const long long row = (long long)d[u].start + 2 * lane;
+          dbl2p sum; sum.x = 0.0; sum.y = 0.0;
+#pragma unroll
+          for (int i = 0; i < PAT_LEN; ++i)
+            if (i < len[u]) {
+              const double v0 = e[u]->v[0][i], v1 = e[u]->v[1][i], v2 = e[u]->v[2][i];
+              const double va = ca == 0 ? v0 : (ca == 1 ? v1 : v2), vb = cb == 0 ? v0 : (cb == 1 ? v1 : v2);
+              sum.x = sum.x + va * xv[u][i].x;
+              sum.y = sum.y + vb * xv[u][i].y;
+            }
+          dbl2p o;
+          if (EPI == 0) {
+            o = sum;
+          } else {
+            dbl2p rr, dg, xr, yy;
+            if (EPI != 3) { const dbl2u q = *reinterpret_cast<const dbl2u*>(rhs + row); rr.x = q.x; rr.y = q.y; }
+            if (EPI == 1 || EPI == 4 || EPI == 5) {
+              const dbl2u q1 = *reinterpret_cast<const dbl2u*>(diag + row), q2 = *reinterpret_cast<const dbl2u*>(x + row);
+              dg.x = q1.x; dg.y = q1.y; xr.x = q2.x; xr.y = q2.y;
+            }
+            if (EPI == 3 || EPI == 4) { const dbl2u q = *reinterpret_cast<const dbl2u*>(y + row); yy.x = q.x; yy.y = q.y; }
+            if (EPI == 2) { o.x = rr.x - sum.x; o.y = rr.y - sum.y; }
+            else if (EPI == 3) { o.x = yy.x + omega * sum.x; o.y = yy.y + omega * sum.y; }
+            else if (EPI == 1) {
+              o.x = dg.x != 0.0 ? xr.x + omega * (rr.x - sum.x) / dg.x : xr.x;
+              o.y = dg.y != 0.0 ? xr.y + omega * (rr.y - sum.y) / dg.y : xr.y;
+            } else if (EPI == 5) {
+              o.x = dg.x != 0.0 ? xr.x + beta * xr.x + omega * (rr.x - sum.x) / dg.x : xr.x;
+              o.y = dg.y != 0.0 ? xr.y + beta * xr.y + omega * (rr.y - sum.y) / dg.y : xr.y;
+            } else {
+              o.x = dg.x != 0.0 ? xr.x + beta * (xr.x - yy.x) + omega * (rr.x - sum.x) / dg.x : xr.x;
+              o.y = dg.y != 0.0 ? xr.y + beta * (xr.y - yy.y) + omega * (rr.y - sum.y) / dg.y : xr.y;
+            }
+          }
+          dbl2u ou; ou.x = o.x; ou.y = o.y;
+          *reinterpret_cast<dbl2u*>(y + row) = ou;
+          if (DOT) { const dbl2u xd = *reinterpret_cast<const dbl2u*>(xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+        }
+    }
+  }
+  if (DOT) pat_block_sum(part, partial, pb);
+}
+
 // the individual rows: one thread per row over the CSR arrays, entries in storage order
 template <bool DOT, int EPI, bool HALO>
 __global__ __launch_bounds__(PAT_BLOCK) void k_spmv_gen(
@@ -566,6 +702,18 @@ template <bool DOT, int EPI, bool HALO>
 void launch_pat_t(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const double* xdot, double* partial,
                   const double* rhs, const double* diag, double omega, double beta, const double* xg, long long nowned,
                   bool pattern_rows, bool generic_rows) {
+  if (a->d_tiledesc) {
+    if (HALO) { mxg_set_error("mxg_pat_launch: the tile product does not read ghosts"); return; }
+    const long long ntb = (a->pat_ntile + TILE_WAVES * TILE_TPW - 1) / (TILE_WAVES * TILE_TPW), ngb = (a->pat_ngrows + 64 * TILE_WAVES - 1) / (64 * TILE_WAVES);
+    const long long ntb8 = ((ntb + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD, ngb8 = ((ngb + 7) / 8) * 8;
+    if (ntb8 + ngb8 > 0)
+      hipLaunchKernelGGL((k_spmv_tile<DOT, EPI>), dim3((unsigned)(ngb8 + ntb8)), dim3(64 * TILE_WAVES), 0, c->stream,
+                         (const TileDesc*)a->d_tiledesc, (const TileEntry*)a->d_tiledict, (long long)a->pat_ntile, ntb, ngb,
+                         (const int*)a->d_grows, (long long)a->pat_ngrows, (const long long*)a->d_rowptr, (const int*)a->d_colidx,
+                         (const double*)a->d_vals, x, y, xdot, partial, rhs, diag, omega, beta,
+                         getenv("MXG_TILE_DIAG_SKIP_IRREGULAR") != nullptr);   // diagnostic: wrong results
+    return;
+  }
   const long long nb = a->d_pairid ? pair_wgs(c, a) : patw_on() ? patw_wgs(c, a) : (a->nrows + PAT_BLOCK - 1) / PAT_BLOCK;
   if (pattern_rows && nb > 0 && a->d_pairid) {
     if (HALO) { mxg_set_error("mxg_pat_launch: the row-pair product does not read ghosts"); return; }
@@ -609,6 +757,10 @@ void launch_pat_t(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const doub
 }  // namespace
 
 int64_t mxg_pat_partials(const mxg_csr* a) {
+  if (a->d_tiledesc) {
+    const int64_t ntb = (a->pat_ntile + TILE_WAVES * TILE_TPW - 1) / (TILE_WAVES * TILE_TPW), ngb = (a->pat_ngrows + 64 * TILE_WAVES - 1) / (64 * TILE_WAVES);
+    return ((ngb + 7) / 8) * 8 + ((ntb + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD;
+  }
   return pat_first_partials(a->ctx, a) + (a->pat_ngrows + PAT_BLOCK - 1) / PAT_BLOCK;
 }
 
@@ -834,5 +986,108 @@ int mxg_pair_build(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doubl
   if (getenv("MXG_PAT_STATS"))
     fprintf(stderr, "[mxg_pat] %lld rows: %lld pair patterns, %lld individual rows (%.2f %%, %lld entries)\n", (long long)n,
             (long long)dict.size(), (long long)grows.size(), 100.0 * grows.size() / std::max<int64_t>(n, 1), (long long)gnnz);
+  return 0;
+}
+
+// Tile form: runs of rows with one length and one list of column offsets in which each row repeats the values of the row
+// three before it, cut into tiles of <= TILE_ROWS rows (a multiple of 6 except at the end of a run, always even).
+int mxg_tile_build(mxg_csr* a, const int64_t* rp, const int32_t* ci, const double* va) {
+  mxg_ctx* c = a->ctx;
+  const int64_t n = a->nrows;
+  // step[r] bit 0: row r has the length and column offsets of row r - 1; bit 1: ... and the values of row r - 3
+  std::vector<unsigned char> step((size_t)std::max<int64_t>(n, 1), 0);
+  auto same_shape = [&](int64_t r, int64_t p) {
+    const int64_t q = rp[r], t = rp[p], len = rp[r + 1] - q;
+    if (rp[p + 1] - t != len || len > PAT_LEN) return false;
+    for (int64_t i = 0; i < len; ++i)
+      if ((int64_t)ci[q + i] - r != (int64_t)ci[t + i] - p) return false;
+    return true;
+  };
+  auto same_vals = [&](int64_t r, int64_t p) {
+    const int64_t q = rp[r], t = rp[p], len = rp[r + 1] - q;
+    return std::memcmp(va + q, va + t, sizeof(double) * (size_t)len) == 0;
+  };
+  {
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (const char* e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) nthreads = (unsigned)v; }
+    if (nthreads > 32) nthreads = 32;
+    if (nthreads < 1 || n < 4096) nthreads = 1;
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i < nthreads; ++i)
+      pool.emplace_back([&, i] {
+        for (int64_t r = std::max<int64_t>(1, n * i / nthreads); r < n * (i + 1) / nthreads; ++r) {
+          unsigned char f = 0;
+          if (rp[r + 1] - rp[r] <= PAT_LEN && same_shape(r, r - 1)) {
+            f = 1;
+            if (r >= 3 && same_shape(r, r - 3) && same_vals(r, r - 3)) f = 3;
+          }
+          step[(size_t)r] = f;
+        }
+      });
+    for (auto& th : pool) th.join();
+  }
+  std::vector<TileDesc> tiles;
+  std::vector<TileEntry> dict;
+  std::unordered_map<std::string, int> ids;
+  std::vector<int32_t> grows;
+  std::string sg;
+  int64_t covered = 0;
+  int64_t r = 0;
+  while (r < n) {
+    // the run that starts at r: rows r+1, r+2 need the shape of their predecessor, later rows also the values of r-3
+    int64_t e = r + 1;
+    if (rp[r + 1] - rp[r] <= PAT_LEN) {
+      while (e < n && (step[(size_t)e] & 1) && (e - r < 3 || (step[(size_t)e] & 2))) ++e;
+    }
+    int64_t len_run = e - r;
+    if (len_run & 1) --len_run;                               // tiles hold an even number of rows
+    if (len_run >= TILE_MIN_RUN) {
+      const int len = (int)(rp[r + 1] - rp[r]);
+      sg.assign(4 + (size_t)len * 4 + (size_t)len * 24, '\0');
+      std::memcpy(&sg[0], &len, 4);
+      TileEntry te{};
+      te.len = len;
+      for (int i = 0; i < len; ++i) {
+        te.delta[i] = (int32_t)((int64_t)ci[rp[r] + i] - r);
+        for (int k = 0; k < 3; ++k) te.v[k][i] = va[rp[r + k] + i];     // len_run >= 24: rows r, r+1, r+2 exist in the run
+        std::memcpy(&sg[4 + (size_t)i * 28], &te.delta[i], 4);
+        for (int k = 0; k < 3; ++k) std::memcpy(&sg[4 + (size_t)i * 28 + 4 + 8 * k], &te.v[k][i], 8);
+      }
+      auto it = ids.find(sg);
+      int id;
+      if (it != ids.end()) id = it->second;
+      else { id = (int)dict.size(); dict.push_back(te); ids.emplace(sg, id); }
+      for (int64_t s0 = r; s0 < r + len_run; s0 += TILE_ROWS) {
+        TileDesc d;
+        d.start = (int)s0; d.nrows = (int)std::min<int64_t>(TILE_ROWS, r + len_run - s0); d.pid = id; d.pad = 0;
+        tiles.push_back(d);
+      }
+      covered += len_run;
+      for (int64_t q = r + len_run; q < e; ++q) grows.push_back((int32_t)q);   // the odd row at the end of the run
+    } else {
+      for (int64_t q = r; q < e; ++q) grows.push_back((int32_t)q);
+    }
+    r = e;
+  }
+  if (a->d_tiledesc) hipFree(a->d_tiledesc);
+  if (a->d_tiledict) hipFree(a->d_tiledict);
+  if (a->d_grows) hipFree(a->d_grows);
+  a->d_tiledesc = nullptr; a->d_tiledict = nullptr; a->d_grows = nullptr;
+  a->pat_tile_coverage = n > 0 ? (double)covered / (double)n : 0.0;
+  if (getenv("MXG_PAT_STATS"))
+    fprintf(stderr, "[mxg_pat] %lld rows: %lld tiles of %lld tile patterns cover %.2f %%, %lld irregular rows\n", (long long)n,
+            (long long)tiles.size(), (long long)dict.size(), 100.0 * a->pat_tile_coverage, (long long)grows.size());
+  const double min_cov = getenv("MXG_TILE_MIN_COVERAGE") ? atof(getenv("MXG_TILE_MIN_COVERAGE")) : 0.80;
+  if (a->pat_tile_coverage < min_cov) { a->pat_ntile = 0; a->pat_ntilepat = 0; return 0; }   // not a lattice operator: keep k_spmv_cs
+  MXG_HIP(hipMalloc(&a->d_tiledesc, sizeof(TileDesc) * std::max<size_t>(tiles.size(), 1)));
+  MXG_HIP(hipMalloc(&a->d_tiledict, sizeof(TileEntry) * std::max<size_t>(dict.size(), 1)));
+  MXG_HIP(hipMalloc(&a->d_grows, sizeof(int32_t) * std::max<size_t>(grows.size(), 1)));
+  if (!tiles.empty()) MXG_HIP(hipMemcpyAsync(a->d_tiledesc, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, c->stream));
+  if (!dict.empty()) MXG_HIP(hipMemcpyAsync(a->d_tiledict, dict.data(), sizeof(TileEntry) * dict.size(), hipMemcpyHostToDevice, c->stream));
+  if (!grows.empty()) MXG_HIP(hipMemcpyAsync(a->d_grows, grows.data(), sizeof(int32_t) * grows.size(), hipMemcpyHostToDevice, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  a->pat_ntile = (int64_t)tiles.size();
+  a->pat_ntilepat = (int64_t)dict.size();
+  a->pat_ngrows = (int64_t)grows.size();
   return 0;
 }

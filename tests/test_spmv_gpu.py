@@ -341,13 +341,17 @@ def test_config3_cylinder_and_config5_sphere_geometries(ctx, rng):
 
 
 # (MXG_PAT, MXG_CSP) at compress time, then launch-time switches of the pattern kernels
-CS_MODES = {"pair": ("2", "0", {}), "pair4": ("2", "0", {"MXG_PAIR_U": "4"}), "pairw": ("2", "0", {"MXG_PAIRW": "1"}),
-            "pat": ("1", "0", {}), "patrow": ("1", "0", {"MXG_PATW": "0"}), "cs": ("0", "0", {}), "csp": ("0", "1", {})}
+CS_MODES = {"tile": ("3", "0", {"MXG_TILE_MIN_COVERAGE": "0"}), "pair": ("2", "0", {}), "pair4": ("2", "0", {"MXG_PAIR_U": "4"}), "pairw": ("2", "0", {"MXG_PAIRW": "1"}),
+            "pat": ("1", "0", {}), "patrow": ("1", "0", {"MXG_PATW": "0"}), "cs": ("0", "0", {}), "csp": ("0", "1", {}), "default": (None, "0", {})}
 
 
 def _cs_env(monkeypatch, mode):
-    monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0]); monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
-    for k in ("MXG_PAIR_U", "MXG_PAIRW", "MXG_PATW"):
+    if CS_MODES[mode][0] is None:
+        monkeypatch.delenv("MXG_PAT", raising=False)
+    else:
+        monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0])
+    monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
+    for k in ("MXG_PAIR_U", "MXG_PAIRW", "MXG_PATW", "MXG_TILE_MIN_COVERAGE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in CS_MODES[mode][2].items():
         monkeypatch.setenv(k, v)
@@ -357,7 +361,8 @@ def _cs_env(monkeypatch, mode):
 def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, mode, monkeypatch):
     """mxg_csr_compress: 16-bit band codes + 8-bit value-table indices per row block; every operator of
     the pillbox (bulk blocks pack, cut-cell blocks fall back to plain CSR rows), SpMV and SpMM, and the
-    fused SpMV+dot of CG give the same bits as the serial row loop.  Modes: "pair" / "pair4" the row-pair pattern product
+    fused SpMV+dot of CG give the same bits as the serial row loop.  Modes: "tile" wavefront-uniform tile patterns through
+    scalar loads, irregular rows in the same launch (k_spmv_tile); "pair" / "pair4" the row-pair pattern product
     (k_spmv_pair with 2 / 4 pairs per lane + k_spmv_gen), "pairw" its wave-persistent form, "pat" the pattern-dictionary
     product (k_spmv_patw + k_spmv_gen), "patrow" one thread per row (k_spmv_pat), "cs" one record per workgroup (k_spmv_cs, the default), "csp" the persistent record
     kernel with a loader wave (k_spmv_csp)."""
