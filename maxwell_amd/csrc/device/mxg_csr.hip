@@ -1587,6 +1587,10 @@ extern "C" int mxg_csr_destroy(mxg_csr* a) {
   if (a->d_patdict) hipFree(a->d_patdict);
   if (a->d_grows) hipFree(a->d_grows);
   if (a->d_pairid) hipFree(a->d_pairid);
+  if (a->d_injcol) hipFree(a->d_injcol);
+  if (a->d_ellcol) hipFree(a->d_ellcol);
+  if (a->d_ellval) hipFree(a->d_ellval);
+  if (a->d_injval) hipFree(a->d_injval);
   if (a->d_tiledesc) hipFree(a->d_tiledesc);
   if (a->d_tiledict) hipFree(a->d_tiledict);
   if (a->d_pairdict) hipFree(a->d_pairdict);
@@ -2491,8 +2495,177 @@ extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg
 
 // Product with a fused epilogue on a compressed matrix (single column, no halo): see cs_epilogue.
 // Returns 1 without touching y when the matrix is not compressed (the caller takes the unfused path).
+// ---- injection matrices (at most one entry per row): y += omega * A x without a matrix stream
+namespace {
+// flags[0] = rows with more than one entry, flags[1] = entries whose value differs from v0
+__global__ void k_inj_build(const long long* __restrict__ rowptr, const int* __restrict__ colidx, const double* __restrict__ vals,
+                            long long nrows, double v0, int* __restrict__ injcol, double* __restrict__ injval,
+                            unsigned long long* __restrict__ flags) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const long long q = rowptr[r], len = rowptr[r + 1] - q;
+  if (len > 1) atomicAdd(&flags[0], 1ull);
+  if (len >= 1) {
+    const double v = vals[q];
+    injcol[r] = colidx[q];
+    injval[r] = v;
+    if (__double_as_longlong(v) != __double_as_longlong(v0)) atomicAdd(&flags[1], 1ull);
+  } else {
+    injcol[r] = -1;
+    injval[r] = 0.0;
+  }
+}
+// y[r] = y[r] + omega * (v * x[c]): the arithmetic of the coarse-correction epilogue (EPI 3) on a one-entry row sum
+template <bool UNIFORM>
+__global__ __launch_bounds__(256) void k_inj_add(const int* __restrict__ injcol, const double* __restrict__ injval, double vu,
+                                                  long long nrows, const double* __restrict__ x, double* __restrict__ y,
+                                                  double omega) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nrows) return;
+  const int cc = injcol[r];
+  const double yy = y[r];
+  double ax = 0.0;
+  if (cc >= 0) ax = 0.0 + (UNIFORM ? vu : injval[r]) * x[cc];
+  y[r] = yy + omega * ax;
+}
+int inj_prepare(mxg_ctx* c, mxg_csr* a) {
+  if (a->inj_state != 0) return 0;
+  a->inj_state = -1;
+  if (a->is_complex || a->nghost != 0 || a->nneigh != 0 || a->nrows == 0 || a->nnz > a->nrows || !a->d_rowptr) return 0;
+  unsigned long long* d_flags = nullptr;
+  MXG_HIP(hipMalloc(&a->d_injcol, sizeof(int32_t) * a->nrows));
+  MXG_HIP(hipMalloc(&a->d_injval, sizeof(double) * a->nrows));
+  MXG_HIP(hipMalloc(&d_flags, sizeof(unsigned long long) * 2));
+  MXG_HIP(hipMemsetAsync(d_flags, 0, sizeof(unsigned long long) * 2, c->stream));
+  double v0 = 0.0;
+  if (a->nnz > 0) MXG_HIP(hipMemcpyAsync(&v0, a->d_vals, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  hipLaunchKernelGGL(k_inj_build, dim3((unsigned)((a->nrows + 255) / 256)), dim3(256), 0, c->stream, (const long long*)a->d_rowptr,
+                     (const int*)a->d_colidx, (const double*)a->d_vals, (long long)a->nrows, v0, a->d_injcol, a->d_injval, d_flags);
+  unsigned long long flags[2] = {1, 1};
+  MXG_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  hipFree(d_flags);
+  if (flags[0] != 0) {                   // some row has two entries: not an injection
+    hipFree(a->d_injcol); hipFree(a->d_injval); a->d_injcol = nullptr; a->d_injval = nullptr;
+    return 0;
+  }
+  if (flags[1] == 0) { hipFree(a->d_injval); a->d_injval = nullptr; a->inj_uniform = v0; }
+  a->inj_state = 1;
+  return 0;
+}
+}  // namespace
+
+// ---- ELL form of short-row gather matrices (multigrid restrictions): columns [width][nrows], coalesced, no row pointers
+namespace {
+// flags[0] = longest row, flags[1] = entries whose value differs from v0
+__global__ void k_ell_scan(const long long* __restrict__ rowptr, const double* __restrict__ vals, long long nrows, double v0,
+                           unsigned long long* __restrict__ flags) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const long long q0 = rowptr[r], q1 = rowptr[r + 1];
+  atomicMax(&flags[0], (unsigned long long)(q1 - q0));
+  unsigned long long diff = 0;
+  for (long long q = q0; q < q1; ++q) diff += __double_as_longlong(vals[q]) != __double_as_longlong(v0);
+  if (diff) atomicAdd(&flags[1], diff);
+}
+__global__ void k_ell_fill(const long long* __restrict__ rowptr, const int* __restrict__ colidx, const double* __restrict__ vals,
+                           long long nrows, int width, int* __restrict__ ecol, double* __restrict__ eval) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const long long q0 = rowptr[r], len = rowptr[r + 1] - q0;
+  for (int j = 0; j < width; ++j) {
+    ecol[(size_t)j * nrows + r] = j < len ? colidx[q0 + j] : -1;
+    if (eval) eval[(size_t)j * nrows + r] = j < len ? vals[q0 + j] : 0.0;
+  }
+}
+// entries in storage order, products rounded before they are added: the row loop of the CSR kernels
+template <bool UNIFORM>
+__global__ __launch_bounds__(256) void k_ell_apply(const int* __restrict__ ecol, const double* __restrict__ eval, double vu,
+                                                    long long nrows, int width, const double* __restrict__ x, double* __restrict__ y) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nrows) return;
+  double sum = 0.0;
+  for (int j0 = 0; j0 < width; j0 += 8) {
+    int cc[8];
+    double vv[8], xx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int jj = j0 + j < width ? j0 + j : width - 1;
+      cc[j] = ecol[(size_t)jj * nrows + r];
+      vv[j] = UNIFORM ? vu : eval[(size_t)jj * nrows + r];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xx[j] = x[cc[j] >= 0 ? cc[j] : 0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double s2 = sum + vv[j] * xx[j];
+      sum = (j0 + j < width && cc[j] >= 0) ? s2 : sum;
+    }
+  }
+  __builtin_nontemporal_store(sum, y + r);
+}
+int ell_prepare(mxg_ctx* c, mxg_csr* a) {
+  if (a->ell_state != 0) return 0;
+  a->ell_state = -1;
+  if (a->is_complex || a->nghost != 0 || a->nneigh != 0 || a->nrows == 0 || a->nnz == 0 || a->ncols_owned < 1 || !a->d_rowptr) return 0;
+  unsigned long long* d_flags = nullptr;
+  MXG_HIP(hipMalloc(&d_flags, sizeof(unsigned long long) * 2));
+  MXG_HIP(hipMemsetAsync(d_flags, 0, sizeof(unsigned long long) * 2, c->stream));
+  double v0 = 0.0;
+  MXG_HIP(hipMemcpyAsync(&v0, a->d_vals, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  const unsigned grid = (unsigned)((a->nrows + 255) / 256);
+  hipLaunchKernelGGL(k_ell_scan, dim3(grid), dim3(256), 0, c->stream, (const long long*)a->d_rowptr, (const double*)a->d_vals,
+                     (long long)a->nrows, v0, d_flags);
+  unsigned long long flags[2] = {1000, 1};
+  MXG_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  hipFree(d_flags);
+  // worth it for short rows only, and only when padding does not blow the matrix up
+  if (flags[0] == 0 || flags[0] > 16 || (double)flags[0] * (double)a->nrows > 1.5 * (double)a->nnz) return 0;
+  a->ell_width = (int)flags[0];
+  const bool uniform = flags[1] == 0;
+  MXG_HIP(hipMalloc(&a->d_ellcol, sizeof(int32_t) * (size_t)a->ell_width * a->nrows));
+  if (!uniform) MXG_HIP(hipMalloc(&a->d_ellval, sizeof(double) * (size_t)a->ell_width * a->nrows));
+  hipLaunchKernelGGL(k_ell_fill, dim3(grid), dim3(256), 0, c->stream, (const long long*)a->d_rowptr, (const int*)a->d_colidx,
+                     (const double*)a->d_vals, (long long)a->nrows, a->ell_width, a->d_ellcol, a->d_ellval);
+  MXG_HIP(hipStreamSynchronize(c->stream));
+  a->ell_uniform = v0;
+  a->ell_state = 1;
+  return 0;
+}
+}  // namespace
+
+int mxg_dev_csr_apply_ell(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y) {
+  if (x->k != 1 || y->k != 1 || x->base == y->base || (getenv("MXG_ELL") && atoi(getenv("MXG_ELL")) == 0)) return 1;
+  if (ell_prepare(c, a) != 0) return 2;
+  if (a->ell_state != 1) return 1;
+  const unsigned grid = (unsigned)((a->nrows + 255) / 256);
+  if (a->d_ellval)
+    hipLaunchKernelGGL((k_ell_apply<false>), dim3(grid), dim3(256), 0, c->stream, (const int*)a->d_ellcol, (const double*)a->d_ellval, 0.0,
+                       (long long)a->nrows, a->ell_width, (const double*)x->colptr(0), y->colptr(0));
+  else
+    hipLaunchKernelGGL((k_ell_apply<true>), dim3(grid), dim3(256), 0, c->stream, (const int*)a->d_ellcol, (const double*)nullptr,
+                       a->ell_uniform, (long long)a->nrows, a->ell_width, (const double*)x->colptr(0), y->colptr(0));
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
                           const double* diag, double omega, double beta) {
+  if (epi == 3 && x->k == 1 && y->k == 1 && x->base != y->base && !(getenv("MXG_INJECT") && atoi(getenv("MXG_INJECT")) == 0)) {
+    if (inj_prepare(c, a) != 0) return 2;
+    if (a->inj_state == 1) {
+      const unsigned grid = (unsigned)((a->nrows + 255) / 256);
+      if (a->d_injval)
+        hipLaunchKernelGGL((k_inj_add<false>), dim3(grid), dim3(256), 0, c->stream, (const int*)a->d_injcol, (const double*)a->d_injval,
+                           0.0, (long long)a->nrows, (const double*)x->colptr(0), y->colptr(0), omega);
+      else
+        hipLaunchKernelGGL((k_inj_add<true>), dim3(grid), dim3(256), 0, c->stream, (const int*)a->d_injcol, (const double*)nullptr,
+                           a->inj_uniform, (long long)a->nrows, (const double*)x->colptr(0), y->colptr(0), omega);
+      return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+  }
   if (cs_halo_ok(a, x, y) && epi != 3) {
     if (halo_start(c, a, x) != 0) return 2;
     if (a->nrows == 0) { hipStreamWaitEvent(c->stream, c->ev_halo, 0); return 0; }

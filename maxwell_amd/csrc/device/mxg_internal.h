@@ -147,6 +147,18 @@ struct mxg_csr {
   unsigned short* d_pairid = nullptr;   // row-pair form of the pattern product (mxg_pat.hip): id per pair of rows
   void* d_pairdict = nullptr;
   int64_t pat_npair = 0;
+  // injection form (every row has at most one entry: the piecewise-constant prolongations of the multigrid): built on
+  // the first product with the coarse-correction epilogue; inj_state 0 unknown, 1 in use, -1 not an injection
+  int inj_state = 0;
+  int32_t* d_injcol = nullptr;          // column of the row's entry, -1 without one
+  double* d_injval = nullptr;           // its value (nullptr when every entry has the value inj_uniform)
+  double inj_uniform = 0.0;
+  // ELL form of a short-row gather matrix (the multigrid restrictions: <= 16 entries per row), built on first use by
+  // mxg_dev_csr_apply_ell; ell_state 0 unknown, 1 in use, -1 not suitable
+  int ell_state = 0, ell_width = 0;
+  int32_t* d_ellcol = nullptr;          // [width][nrows], -1 = no entry
+  double* d_ellval = nullptr;           // [width][nrows]; nullptr when every entry has the value ell_uniform
+  double ell_uniform = 0.0;
   void* d_tiledesc = nullptr;           // tile form of the pattern product (mxg_pat.hip, MXG_PAT=3): 16-byte tile descriptors,
   void* d_tiledict = nullptr;           // wavefront-uniform tile patterns; irregular rows in d_grows
   int64_t pat_ntile = 0, pat_ntilepat = 0;
@@ -195,6 +207,8 @@ int mxg_ctx_finish_reduce(mxg_ctx* ctx, size_t width, double* host_out);
 // device-side entry points used across translation units (results stay on device)
 // d_out[j] = sum_i conj(A_j[i]) * B_j[i]; complex results interleaved. No all-reduce, no sync.
 int mxg_dev_dot(mxg_ctx* ctx, const MvDesc& A, const MvDesc& B, double* d_out);
+// y = A x through the ELL form of a short-row matrix (0 done, 1 not applicable: use mxg_csr_apply, 2 error)
+int mxg_dev_csr_apply_ell(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y);
 
 // y = A x with the p.Ap of CG fused in (mxg_csr.hip); d_out is a device scalar
 // 0: launched; 1: matrix not compressed / shape not supported (nothing done); 2: launch error

@@ -320,7 +320,11 @@ int mg_cycle(mxg_mg* mg, int l) {
     hipLaunchKernelGGL(k_resid, dim3(grid), dim3(256), 0, c->stream, n, (const double*)mg->r[l]->colptr(0),
                        mg->t[l]->colptr(0));                                      // t = r - A z
   }
-  MXG_TRY(mxg_csr_apply(c, mg->R[l], mg->t[l], mg->r[l + 1]));                    // restrict
+  {                                                                              // restrict (ELL form of R when it has one)
+    const int rr = mxg_dev_csr_apply_ell(c, mg->R[l], mg->t[l], mg->r[l + 1]);
+    if (rr > 1) return 1;
+    if (rr == 1) MXG_TRY(mxg_csr_apply(c, mg->R[l], mg->t[l], mg->r[l + 1]));
+  }
   MXG_TRY(mg_cycle(mg, l + 1));
   // z += cscale * P z_c: in the prolongation's epilogue when P is compressed (in place: a row reads only its own z)
   const int rp = mxg_dev_csr_apply_epi(c, mg->P[l], mg->z[l + 1], mg->z[l], 3, nullptr, nullptr, mg->cscale);
