@@ -2526,7 +2526,7 @@ __global__ __launch_bounds__(256) void k_inj_add(const int* __restrict__ injcol,
   const double yy = y[r];
   double ax = 0.0;
   if (cc >= 0) ax = 0.0 + (UNIFORM ? vu : injval[r]) * x[cc];
-  y[r] = yy + omega * ax;
+  __builtin_nontemporal_store(yy + omega * ax, y + r);   // keep the coarse vector's lines in L2, not the streamed y
 }
 int inj_prepare(mxg_ctx* c, mxg_csr* a) {
   if (a->inj_state != 0) return 0;

@@ -520,16 +520,23 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_spmv_tile(
     const int* __restrict__ grows, long long ngrows, const long long* __restrict__ rowptr, const int* __restrict__ colidx,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ xdot,
     double* __restrict__ partial, const double* __restrict__ rhs, const double* __restrict__ diag, double omega, double beta,
-    bool skipgen) {
+    bool skipgen, bool spread) {
   double part = 0.0;
   const long long pb = blockIdx.x;                                   // partial slot
   // The first ngb8 workgroups walk the irregular rows (measured: better than spreading them among the tile groups,
   // 0.143 against 0.173 ms - while they are resident they take wave slots from the streaming tiles either way)
   const long long ngb8 = ((ngb + 7) / 8) * 8;
-  const bool gen_group = (long long)blockIdx.x < ngb8;
+  // spread: groups of 8 workgroups (one per XCD); the ngg groups of irregular rows are placed evenly among the tile groups,
+  // i.e. next to the tiles of the same part of the matrix
+  const long long ngg = ngb8 / 8, ntg = (ntb + 7) / 8, G = blockIdx.x / 8;
+  const long long gs = (spread && ngg > 0) ? max(1LL, (ngg + ntg) / ngg) : 1;
+  const long long gq = G / gs;
+  const bool gen_group = spread ? (ngg > 0 && G % gs == 0 && gq < ngg) : (long long)blockIdx.x < ngb8;
+  const long long gen_block = spread ? gq * 8 + blockIdx.x % 8 : (long long)blockIdx.x;
+  const long long tile_block = spread ? (G - (ngg > 0 ? min(ngg, gq + 1) : 0)) * 8 + blockIdx.x % 8 : (long long)blockIdx.x - ngb8;
   if (gen_group) {
     // ---- irregular rows: one thread per row over the CSR arrays
-    const long long i = (long long)blockIdx.x * (64 * TILE_WAVES) + threadIdx.x;
+    const long long i = gen_block * (64 * TILE_WAVES) + threadIdx.x;
     if (i < ngrows && !skipgen) {
       const long long row = grows[i];
       const long long q0 = rowptr[row], q1 = rowptr[row + 1];
@@ -551,11 +558,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_spmv_tile(
           sum = q + j < q1 ? s2 : sum;
         }
       }
-      y[row] = pat_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y);
+      __builtin_nontemporal_store(pat_epilogue<EPI>(sum, row, x, rhs, diag, omega, beta, y), y + row);
       if (DOT) part = sum * xdot[row];
     }
   } else {
-    const long long tb = pat_xcd_block((long long)blockIdx.x - ngb8, ntb);   // XCD w % 8 walks a contiguous eighth of the tiles
+    const long long tb = pat_xcd_block(tile_block, ntb);   // XCD w % 8 walks a contiguous eighth of the tiles
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long long t0 = (tb * TILE_WAVES + wave) * TILE_TPW;       // TILE_TPW consecutive tiles per wavefront
     if (tb < ntb && t0 < ntiles) {
@@ -621,8 +628,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_spmv_tile(
               o.y = dg.y != 0.0 ? xr.y + beta * (xr.y - yy.y) + omega * (rr.y - sum.y) / dg.y : xr.y;
             }
           }
+          // non-temporal: a plain store allocates the line in L2 and evicts the x windows the neighbouring tiles are
+          // about to gather - measured 0.105 against 0.054 ms on the tile rows (scripts/ubench_gather.hip, v6)
           dbl2u ou; ou.x = o.x; ou.y = o.y;
-          *reinterpret_cast<dbl2u*>(y + row) = ou;
+          __builtin_nontemporal_store(ou, reinterpret_cast<dbl2u*>(y + row));
           if (DOT) { const dbl2u xd = *reinterpret_cast<const dbl2u*>(xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
         }
     }
@@ -711,7 +720,8 @@ void launch_pat_t(mxg_ctx* c, mxg_csr* a, const double* x, double* y, const doub
                          (const TileDesc*)a->d_tiledesc, (const TileEntry*)a->d_tiledict, (long long)a->pat_ntile, ntb, ngb,
                          (const int*)a->d_grows, (long long)a->pat_ngrows, (const long long*)a->d_rowptr, (const int*)a->d_colidx,
                          (const double*)a->d_vals, x, y, xdot, partial, rhs, diag, omega, beta,
-                         getenv("MXG_TILE_DIAG_SKIP_IRREGULAR") != nullptr);   // diagnostic: wrong results
+                         getenv("MXG_TILE_DIAG_SKIP_IRREGULAR") != nullptr,    // diagnostic: wrong results
+                         getenv("MXG_TILE_SPREAD") != nullptr && atoi(getenv("MXG_TILE_SPREAD")) != 0);
     return;
   }
   const long long nb = a->d_pairid ? pair_wgs(c, a) : patw_on() ? patw_wgs(c, a) : (a->nrows + PAT_BLOCK - 1) / PAT_BLOCK;

@@ -24,7 +24,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "worker":
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else "256"
     for op in ("vecLapl", "scaLapl"):
-        for env in ({}, {"MXG_PAT": "3", "MXG_PAT_STATS": "1"}, {"MXG_PAT": "3", "MXG_TILE_DIAG_SKIP_IRREGULAR": "1"}):
+        for env in ({}, {"MXG_TILE_SPREAD": "1"}):
             r = subprocess.run([sys.executable, __file__, "worker", n, op], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
             out = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
             print(out[0] if out else "FAILED rc=%d %s" % (r.returncode, (r.stdout + r.stderr)[-600:]), flush=True)

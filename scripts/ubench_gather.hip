@@ -205,6 +205,46 @@ __global__ __launch_bounds__(256) void k_v5(const unsigned short* __restrict__ p
   }
 }
 
+// v6: the tile product of mxg_pat.hip on synthetic tiles that cover every row: descriptor {start, rows, pattern} and the
+// pattern through scalar loads, two rows per lane, 63 lanes per tile.  MODE 0: as in the library; 1: descriptor
+// computed instead of loaded (start = lo + t * 126); 2: also the pattern from kernel arguments (no dependent scalar load).
+struct TileDesc { int start, nrows, pid, pad; };
+struct TileEntry { int len, pad0[7]; int delta[8]; double v[3][8]; };
+template <int MODE, int WAVES, int TROWS = 126, bool NT = false>
+__global__ __launch_bounds__(64 * WAVES) void k_v6(const TileDesc* __restrict__ desc, const TileEntry* __restrict__ dict, long long ntiles,
+                                                    long long ntb, const double* __restrict__ x, double* __restrict__ y, long long lo, Legs L) {
+  const long long tb = xcd_block(blockIdx.x, ntb);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const long long t = tb * WAVES + wave;
+  if (tb >= ntb || t >= ntiles) return;
+  TileDesc d;
+  if (MODE == 0) d = desc[t]; else { d.start = (int)(lo + t * TROWS); d.nrows = TROWS; d.pid = (int)(t % 3); }
+  const TileEntry* e = dict + d.pid;
+  const int len = MODE == 2 ? 7 : e->len;
+  if (2 * lane >= d.nrows) return;
+  const int ca = (2 * lane) % 3, cb = (2 * lane + 1) % 3;
+  dbl2 xv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < len) {
+      const long long off = MODE == 2 ? L.off[i] : (long long)e->delta[i];
+      const double* xp = x + ((long long)d.start + off);
+      const dbl2u tt = *reinterpret_cast<const dbl2u*>(xp + 2 * lane);
+      xv[i].x = tt.x; xv[i].y = tt.y;
+    }
+  double sa = 0.0, sb = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < len) {
+      double v0, v1, v2;
+      if (MODE == 2) { v0 = v1 = v2 = L.c[i]; } else { v0 = e->v[0][i]; v1 = e->v[1][i]; v2 = e->v[2][i]; }
+      const double va = ca == 0 ? v0 : (ca == 1 ? v1 : v2), vb = cb == 0 ? v0 : (cb == 1 ? v1 : v2);
+      sa += va * xv[i].x; sb += vb * xv[i].y;
+    }
+  if (NT) { dbl2 o; o.x = sa; o.y = sb; __builtin_nontemporal_store(o, reinterpret_cast<dbl2*>(y + (long long)d.start + 2 * lane)); }
+  else { dbl2u o; o.x = sa; o.y = sb; *reinterpret_cast<dbl2u*>(y + (long long)d.start + 2 * lane) = o; }
+}
+
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 189;                 // 3 * 190^3 = 20.6 M rows
   const long long M = N + 1, sy = 3 * M, sz = 3 * M * M, n = 3 * M * M * M;
@@ -314,6 +354,48 @@ int main(int argc, char** argv) {
     for (int w : {2, 3}) v5(k_v5<3, true>, 3, w, "v5 pipelined pair product, U = 3");
     v5(k_v5<1, true>, 1, 4, "v5 pipelined pair product, U = 1");
     v5(k_v5<1, true>, 1, 6, "v5 pipelined pair product, U = 1");
+  }
+  // v6
+  {
+    const long long ntiles = (hi - lo - 256) / 126;
+    std::vector<TileDesc> ht(ntiles);
+    for (long long t = 0; t < ntiles; ++t) { ht[t].start = (int)(lo + t * 126); ht[t].nrows = 126; ht[t].pid = (int)(t % 3); ht[t].pad = 0; }
+    std::vector<TileEntry> hd(3);
+    for (int k = 0; k < 3; ++k) {
+      TileEntry e{}; e.len = 7;
+      for (int i = 0; i < 7; ++i) { e.delta[i] = (int)far.off[i]; for (int c = 0; c < 3; ++c) e.v[c][i] = far.c[i]; }
+      hd[k] = e;
+    }
+    TileDesc* dt; TileEntry* dd;
+    CHECK(hipMalloc(&dt, sizeof(TileDesc) * ntiles)); CHECK(hipMalloc(&dd, sizeof(TileEntry) * 3));
+    CHECK(hipMemcpy(dt, ht.data(), sizeof(TileDesc) * ntiles, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dd, hd.data(), sizeof(TileEntry) * 3, hipMemcpyHostToDevice));
+    auto v6 = [&](auto kern, int waves, const char* name) {
+      const long long ntb = (ntiles + waves - 1) / waves;
+      const unsigned g = (unsigned)(((ntb + NXCD - 1) / NXCD) * NXCD);
+      run(name, [&] { hipLaunchKernelGGL(kern, dim3(g), dim3(64 * waves), 0, 0, dt, dd, ntiles, ntb, x, y, lo, far); }, (double)ntiles * 126);
+      std::vector<double> a(504), b(504);
+      CHECK(hipMemcpy(b.data(), y + lo + 126 * 50, sizeof(double) * 504, hipMemcpyDeviceToHost));
+      hipLaunchKernelGGL(k_v0, dim3(grid), dim3(256), 0, 0, x, y, n, lo, hi, far, nb);
+      CHECK(hipMemcpy(a.data(), y + lo + 126 * 50, sizeof(double) * 504, hipMemcpyDeviceToHost));
+      int bad = 0; for (int i = 0; i < 504; ++i) bad += a[i] != b[i];
+      if (bad) printf("   mismatches against v0 on 504 rows: %d\n", bad);
+    };
+    auto v6b = [&](auto kern, int waves, int trows, const char* name) {
+      const long long nt2 = (hi - lo - 256) / trows, ntb = (nt2 + waves - 1) / waves;
+      const unsigned g = (unsigned)(((ntb + NXCD - 1) / NXCD) * NXCD);
+      run(name, [&] { hipLaunchKernelGGL(kern, dim3(g), dim3(64 * waves), 0, 0, dt, dd, nt2, ntb, x, y, lo, far); }, (double)nt2 * trows);
+    };
+    v6b(k_v6<2, 4, 128, false>, 4, 128, "v6 computed, 128-row tiles (64 lanes, aligned)");
+    v6b(k_v6<2, 4, 128, true>, 4, 128, "v6 computed, 128-row tiles, nontemporal store");
+    v6b(k_v6<2, 4, 126, true>, 4, 126, "v6 computed, 126-row tiles, nontemporal store");
+    v6b(k_v6<2, 2, 128, true>, 2, 128, "v6 computed, 128-row tiles, nontemporal store, 2 waves/WG");
+    v6(k_v6<0, 4>, 4, "v6 tile product, descriptor + pattern loaded, 4 waves/WG");
+    v6(k_v6<1, 4>, 4, "v6 descriptor computed, pattern loaded");
+    v6(k_v6<2, 4>, 4, "v6 descriptor computed, pattern in kernel args");
+    v6(k_v6<0, 2>, 2, "v6 tile product, 2 waves/WG");
+    v6(k_v6<0, 8>, 8, "v6 tile product, 8 waves/WG");
+    v6(k_v6<0, 1>, 1, "v6 tile product, 1 wave/WG");
   }
   return 0;
 }
