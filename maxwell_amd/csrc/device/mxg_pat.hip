@@ -507,7 +507,9 @@ __global__ __launch_bounds__(64 * PAIR_WAVES) void k_spmv_pairw(
 // ends, runs shorter than TILE_MIN_RUN) are walked over the CSR arrays by the first workgroups of the SAME launch.
 struct TileDesc { int start, nrows, pid, pad; };                     // 16 bytes
 struct TileEntry {                                                   // 256 bytes
-  int len, pad0[7];
+  int len;
+  int dslot;                                                         // index of the diagonal entry (offset 0), -1 without one
+  int pad0[6];
   int delta[PAT_LEN];
   double v[3][PAT_LEN];
 };
@@ -611,8 +613,17 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_spmv_tile(
             dbl2p rr, dg, xr, yy;
             if (EPI != 3) { const dbl2u q = *reinterpret_cast<const dbl2u*>(rhs + row); rr.x = q.x; rr.y = q.y; }
             if (EPI == 1 || EPI == 4 || EPI == 5) {
-              const dbl2u q1 = *reinterpret_cast<const dbl2u*>(diag + row), q2 = *reinterpret_cast<const dbl2u*>(x + row);
-              dg.x = q1.x; dg.y = q1.y; xr.x = q2.x; xr.y = q2.y;
+              const dbl2u q2 = *reinterpret_cast<const dbl2u*>(x + row);
+              xr.x = q2.x; xr.y = q2.y;
+              const int ds = e[u]->dslot;                             // uniform
+              if (ds >= 0) {                                          // the diagonal is an entry of the pattern: no load
+                const double d0 = e[u]->v[0][ds], d1 = e[u]->v[1][ds], d2 = e[u]->v[2][ds];
+                dg.x = ca == 0 ? d0 : (ca == 1 ? d1 : d2);
+                dg.y = cb == 0 ? d0 : (cb == 1 ? d1 : d2);
+              } else {
+                const dbl2u q1 = *reinterpret_cast<const dbl2u*>(diag + row);
+                dg.x = q1.x; dg.y = q1.y;
+              }
             }
             if (EPI == 3 || EPI == 4) { const dbl2u q = *reinterpret_cast<const dbl2u*>(y + row); yy.x = q.x; yy.y = q.y; }
             if (EPI == 2) { o.x = rr.x - sum.x; o.y = rr.y - sum.y; }
@@ -1057,12 +1068,16 @@ int mxg_tile_build(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doubl
       std::memcpy(&sg[0], &len, 4);
       TileEntry te{};
       te.len = len;
+      te.dslot = -1;
+      int ndiag = 0;
       for (int i = 0; i < len; ++i) {
         te.delta[i] = (int32_t)((int64_t)ci[rp[r] + i] - r);
+        if (te.delta[i] == 0) { te.dslot = i; ++ndiag; }
         for (int k = 0; k < 3; ++k) te.v[k][i] = va[rp[r + k] + i];     // len_run >= 24: rows r, r+1, r+2 exist in the run
         std::memcpy(&sg[4 + (size_t)i * 28], &te.delta[i], 4);
         for (int k = 0; k < 3; ++k) std::memcpy(&sg[4 + (size_t)i * 28 + 4 + 8 * k], &te.v[k][i], 8);
       }
+      if (ndiag != 1) te.dslot = -1;                            // d_diag sums repeated diagonal entries: read it then
       auto it = ids.find(sg);
       int id;
       if (it != ids.end()) id = it->second;
