@@ -1550,8 +1550,20 @@ int mxg_csr_adopt_device(mxg_ctx* c, int64_t nrows, int64_t ncols, int64_t nnz, 
   a->nrows = nrows; a->ncols_owned = ncols; a->nghost = 0; a->nnz = nnz;
   a->is_complex = 0;
   a->d_rowptr = d_rowptr; a->d_colidx = d_colidx; a->d_vals = d_vals;
+  a->kernel = MXG_KERNEL_DEFAULT;
+  a->lazy = 1;
+  *out = a;
+  if (getenv("MXG_LAZY_ADOPT") && atoi(getenv("MXG_LAZY_ADOPT")) == 0) return mxg_csr_materialize(a);
+  return 0;
+}
+
+int mxg_csr_materialize(mxg_csr* a) {
+  if (!a || !a->lazy) return 0;
+  a->lazy = 0;
+  mxg_ctx* c = a->ctx;
+  const int64_t nrows = a->nrows, nnz = a->nnz;
   std::vector<int64_t> rp((size_t)nrows + 1);
-  MXG_HIP(hipMemcpyAsync(rp.data(), d_rowptr, sizeof(int64_t) * (nrows + 1), hipMemcpyDeviceToHost, c->stream));
+  MXG_HIP(hipMemcpyAsync(rp.data(), a->d_rowptr, sizeof(int64_t) * (nrows + 1), hipMemcpyDeviceToHost, c->stream));
   MXG_HIP(hipStreamSynchronize(c->stream));
   std::vector<int32_t> blk = build_row_blocks(rp.data(), nrows, CfgDefault::NNZ_CAP, CfgDefault::ROWS_BLK);
   a->nblocks = (int64_t)blk.size() - 1;
@@ -1564,10 +1576,8 @@ int mxg_csr_adopt_device(mxg_ctx* c, int64_t nrows, int64_t ncols, int64_t nnz, 
     MXG_HIP(hipGetLastError());
   }
   MXG_HIP(hipStreamSynchronize(c->stream));
-  a->kernel = MXG_KERNEL_DEFAULT;
   if (nnz > 0) MXG_TRY(build_pipe_desc(a, 10, rp.data()));
   else { a->pipe_geo = 10; a->npipe = 0; }
-  *out = a;
   return 0;
 }
 
@@ -2074,6 +2084,7 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
 
 extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals,
                                      int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(a)));
   MXG_CHECK(a, "mxg_csr_compress: NULL argument");
   MXG_CHECK(!a->is_complex, "mxg_csr_compress: real matrices only");
   mxg_ctx* c = a->ctx;
@@ -2111,10 +2122,12 @@ extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const in
 }
 
 extern "C" int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(a)));
   return mxg_csr_compress_from(a, nullptr, nullptr, nullptr, nblocks, nfallback, stream_bytes);
 }
 
 extern "C" int mxg_csr_set_kernel(mxg_csr* a, int which) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(a)));
   const int old_geo = (a->kernel >> 4) & 3, geo = (which >> 4) & 3;
   a->kernel = which;
   if ((which & 0x30000) && !a->is_complex) {   // row-gather kernel: 0x10000 = 2048 nnz, 0x20000 = 3072 nnz
@@ -2323,6 +2336,7 @@ static inline bool cs_halo_ok(const mxg_csr* a, const mxg_mv* x, const mxg_mv* y
 }
 
 extern "C" int mxg_csr_apply(mxg_ctx* c, const mxg_csr* a_, const mxg_mv* x, mxg_mv* y) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(a_)));
   mxg_csr* a = const_cast<mxg_csr*>(a_);
   MXG_CHECK(c && a && x && y, "mxg_csr_apply: NULL argument");
   MXG_CHECK(x->k == y->k, "mxg_csr_apply: x has %d columns, y has %d", x->k, y->k);
@@ -2653,6 +2667,7 @@ int mxg_dev_csr_apply_ell(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y) {
 
 int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
                           const double* diag, double omega, double beta) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(a)));
   if (epi == 3 && x->k == 1 && y->k == 1 && x->base != y->base && !(getenv("MXG_INJECT") && atoi(getenv("MXG_INJECT")) == 0)) {
     if (inj_prepare(c, a) != 0) return 2;
     if (a->inj_state == 1) {
@@ -2714,6 +2729,7 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
 // y = A x and d_out[0] = x . y in one pass over the matrix (real, one column, row-gather geometry).
 // x . y uses the owned rows only; the caller all-reduces d_out across ranks if needed.
 int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(a)));
   MXG_CHECK(!a->is_complex && x->k == 1 && y->k == 1 && a->nrows == a->ncols_owned,
             "mxg_dev_csr_apply_dot: real square single-column case only");
   MXG_CHECK(a->pipe_geo == 10, "mxg_dev_csr_apply_dot: row-gather descriptors missing");

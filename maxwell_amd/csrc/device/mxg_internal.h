@@ -159,6 +159,10 @@ struct mxg_csr {
   int32_t* d_ellcol = nullptr;          // [width][nrows], -1 = no entry
   double* d_ellval = nullptr;           // [width][nrows]; nullptr when every entry has the value ell_uniform
   double ell_uniform = 0.0;
+  // a matrix adopted from device arrays (the results of mxg_csr_multiply / add / purge) gets its apply-side structures
+  // (row blocks, diagonal, pipeline descriptors) only when something applies / compresses it: the intermediates of the
+  // operator chain never do (mxg_csr_materialize)
+  int lazy = 0;
   void* d_tiledesc = nullptr;           // tile form of the pattern product (mxg_pat.hip, MXG_PAT=3): 16-byte tile descriptors,
   void* d_tiledict = nullptr;           // wavefront-uniform tile patterns; irregular rows in d_grows
   int64_t pat_ntile = 0, pat_ntilepat = 0;
@@ -207,6 +211,8 @@ int mxg_ctx_finish_reduce(mxg_ctx* ctx, size_t width, double* host_out);
 // device-side entry points used across translation units (results stay on device)
 // d_out[j] = sum_i conj(A_j[i]) * B_j[i]; complex results interleaved. No all-reduce, no sync.
 int mxg_dev_dot(mxg_ctx* ctx, const MvDesc& A, const MvDesc& B, double* d_out);
+// build the apply-side structures of an adopted matrix if that has not happened yet
+int mxg_csr_materialize(mxg_csr* a);
 // y = A x through the ELL form of a short-row matrix (0 done, 1 not applicable: use mxg_csr_apply, 2 error)
 int mxg_dev_csr_apply_ell(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y);
 

@@ -343,6 +343,11 @@ int mg_cycle(mxg_mg* mg, int l) {
 extern "C" int mxg_mg_create(mxg_ctx* c, int nlevels, mxg_csr* const* A, mxg_csr* const* P,
                              mxg_csr* const* R, int pre, int post, int coarse, double omega,
                              double cscale, mxg_mg** out) {
+  for (int l = 0; l < nlevels; ++l) {
+    if (A && A[l]) MXG_TRY(mxg_csr_materialize(A[l]));
+    if (l + 1 < nlevels && P && P[l]) MXG_TRY(mxg_csr_materialize(P[l]));
+    if (l + 1 < nlevels && R && R[l]) MXG_TRY(mxg_csr_materialize(R[l]));
+  }
   MXG_CHECK(c && A && out && nlevels >= 1, "mxg_mg_create: bad argument");
   MXG_CHECK(pre == post, "mxg_mg_create: pre and post sweeps must be equal (symmetric cycle for CG)");
   mxg_mg* mg = new mxg_mg();
@@ -590,6 +595,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
 
 extern "C" int mxg_solve_cg(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
                             const mxg_solve_opts* o, mxg_solve_info* info) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(A)));
   MXG_CHECK(c && A && b && x && o && info, "mxg_solve_cg: NULL argument");
   MXG_CHECK(A->nrows == A->ncols_owned, "mxg_solve_cg: matrix must be square");
   MXG_CHECK(b->k == x->k && b->nlocal == A->nrows && x->nlocal == A->nrows,
@@ -658,6 +664,7 @@ extern "C" int mxg_solve_cg(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_m
 // iteration, no basis to orthogonalise against.  Stops on the unscaled true residual like the other solvers.
 extern "C" int mxg_solve_bicgstab(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
                                   const mxg_solve_opts* o, mxg_solve_info* info) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(A)));
   MXG_CHECK(c && A && b && x && o && info, "mxg_solve_bicgstab: NULL argument");
   MXG_CHECK(A->nrows == A->ncols_owned, "mxg_solve_bicgstab: matrix must be square");
   MXG_CHECK(b->k == x->k && b->nlocal == A->nrows && x->nlocal == A->nrows, "mxg_solve_bicgstab: shape mismatch");
@@ -732,6 +739,7 @@ extern "C" int mxg_solve_bicgstab(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b,
 
 extern "C" int mxg_solve_gmres(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
                                const mxg_solve_opts* o, mxg_solve_info* info) {
+  MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(A)));
   MXG_CHECK(c && A && b && x && o && info, "mxg_solve_gmres: NULL argument");
   MXG_CHECK(A->nrows == A->ncols_owned, "mxg_solve_gmres: matrix must be square");
   MXG_CHECK(b->k == x->k && b->nlocal == A->nrows && x->nlocal == A->nrows,
