@@ -421,7 +421,10 @@ def test_compressed_stream_fallbacks(ctx, rng, mode, monkeypatch):
     want = cref.spmv(m, x)
     A = mx.CsrMatrix.from_scipy(ctx, m)
     nb, nf, nbytes = A.compress()
-    assert 0 < nf < nb                                    # both kinds of blocks are present
+    if mode == "tile":                                    # forced tile form (coverage threshold 0): tiles + irregular rows, no records
+        assert nb > 0 and nf == 0 and A.product_form()[0] == 3
+    else:
+        assert 0 < nf < nb                                # both kinds of blocks are present
     X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, n, 1)
     A.apply(X, Y)
     got = Y.to_numpy()[:, 0]
