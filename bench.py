@@ -39,12 +39,13 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--cells", dest="n", type=int, default=256, help="Yee cells per side (per GPU)")
     p.add_argument("--k", type=int, default=1, help="vectors in the block (SpMM when > 1)")
-    p.add_argument("--kernel", type=lambda v: int(v, 0), default=-1, help="SpMV kernel variant code (default: library default)")
+    p.add_argument("--kernel", type=lambda v: int(v, 0), default=-1, help="CSR kernel: 0 default, 1 int64 row pointers (mxg_csr_set_kernel)")
     p.add_argument("--eig-n", type=int, default=256, help="grid of the eigenpairs/s measurement (0 = skip)")
     p.add_argument("--eig-timeout", type=int, default=420, help="N > 1: seconds the decomposed eigen-solve may take")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
     p.add_argument("--cpu-eig-n", type=int, default=28, help="grid of the CPU eigenpairs/s sample (sparse direct shift-invert)")
-    p.add_argument("--no-compressed", action="store_true", help="skip the compressed-stream side measurement")
+    p.add_argument("--no-compressed", action="store_true", help="skip the compressed-stream / tile-product side measurements")
+    p.add_argument("--spmm-k", type=int, default=8, help="block of vectors of the tile-product SpMM side measurement (0 = skip)")
     p.add_argument("--dist-selftest", action="store_true",
                    help="run the N > 1 code path (torch.distributed + RCCL ctx + box assembly + halo plan) on 1 rank")
     return p.parse_args()
@@ -260,7 +261,7 @@ def main():
                    "setup_seconds": round(setup_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "k_spmv_rowgather<RgCfg<256,2048>,7> (16-bit in-block row offsets, branch-free row walk)" if args.kernel < 0 else "variant %#x" % args.kernel,
+                     "kernel": A.kernel_name(),
                      "kernel_ms": round(kern_ms, 5),
                      "algorithmic_bytes_per_launch": alg // world,
                      "note": "achieved = nnz*12 + rows*(8+8k) + cols*8k bytes (SURVEY 8d CSR formula) / HIP-event time per "
@@ -269,6 +270,7 @@ def main():
     }
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
     # (scripts/gpu_suite.sh); the latest committed summary for this workload is attached
+    hbm_summary = None
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_counters.json")))[::-1]:
@@ -276,9 +278,23 @@ def main():
             if h.get("workload", {}).get("rows") == rows // max(world, 1) and args.kernel < 0 and args.k == 1:
                 out["roofline"]["traffic"] = int(h["hbm_bytes_per_launch"]["total"])
                 out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE)"
+                hbm_summary = (h, os.path.relpath(f, ROOT))
                 break
     except Exception:
         pass
+    # what a pure stream with the product's byte mix reaches on THIS device in THIS run (the devices of the pool differ
+    # by several per cent): the matrix stream + x read once, y written once, no gathers
+    try:
+        if rank == 0:
+            per = alg // world
+            wbytes = (A.nrows * 8 * args.k) // 16 * 16
+            sms = ctx.stream_ceiling_ms(per - wbytes, wbytes, 20)
+            out["roofline"]["stream_ceiling"] = {"GBps": round(per / (sms * 1e-3) / 1e9, 1), "ms": round(sms, 5),
+                                                 "frac_of_peak": round(per / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "kernel_frac_of_ceiling": round(sms / kern_ms, 4),
+                                                 "what": "mxg_bench_stream: the same bytes read (16-byte non-temporal loads) and written once, no gathers, same device, same run"}
+    except Exception as e:
+        out["roofline"]["stream_ceiling"] = {"error": str(e)}
     if rank == 0 and args.cpu_seconds > 0 and world == 1 and not args.dist_selftest:
         out["cpu_baseline"] = cpu_baseline(sim, shift, A.nrows, alg, args.cpu_seconds)
         try:
@@ -292,7 +308,7 @@ def main():
         # the headline, which stays on the plain CSR arrays: "effective" divides the CSR formula's bytes by the time, the
         # kernels themselves move far fewer.  Two forms: the compressed stream (16-bit band codes + 8-bit value ids,
         # k_spmv_cs: any matrix) and the tile patterns the eigen-driver runs on lattice operators (k_spmv_tile: 16 B of
-        # descriptor per 126 rows, patterns through scalar loads, irregular rows over the CSR arrays in the same launch).
+        # descriptor per 126 rows, patterns through scalar loads, irregular rows as ELL groups in the same launch).
         A.apply(X, Y)
         ref = Y.to_numpy()
         for key, pat in (("compressed_stream", "0"), ("tile_product", None)):
@@ -313,13 +329,36 @@ def main():
                 cms = ctx.timer_stop() / args.steps
                 same = bool(np.array_equal(ref, Yc.to_numpy()))
                 if form == 3:
-                    moved = ntile * 16 + int((1.0 - cov) * Ac.nnz) * 12 + nirr * 20 + Ac.nrows * 8 * args.k + Ac.ncols * 8 * args.k
-                    out[key] = {"kernel": "k_spmv_tile (wavefront-uniform tile patterns, scalar loads; irregular rows in the same launch)",
+                    # bytes of the form (descriptors, patterns, ELL groups of the irregular rows) + x read once + y written once
+                    moved = nbytes + Ac.nrows * 8 * args.k + Ac.ncols * 8 * args.k
+                    out[key] = {"kernel": Ac.kernel_name() + " (wavefront-uniform tile patterns, scalar loads; irregular rows as ELL groups in the same launch)",
                                 "kernel_ms": round(cms, 5), "speedup_vs_csr": round(kern_ms / cms, 3),
                                 "effective_GBps": round(alg / (cms * 1e-3) / 1e9, 1), "bytes_moved_per_launch": int(moved),
                                 "hbm_GBps": round(moved / (cms * 1e-3) / 1e9, 1), "hbm_frac_of_peak": round(moved / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                 "tiles": ntile, "tile_patterns": npat, "irregular_rows": nirr, "row_coverage": round(cov, 4),
-                                "setup_seconds": round(tcomp, 2), "bit_identical_to_csr": same}
+                                "form_bytes": nbytes, "setup_seconds": round(tcomp, 2), "bit_identical_to_csr": same}
+                    if hbm_summary and "k_spmv_tile" in hbm_summary[0].get("kernels", {}):
+                        tk = hbm_summary[0]["kernels"]["k_spmv_tile"]
+                        out[key]["traffic"] = int(tk["total"])
+                        out[key]["traffic_source"] = hbm_summary[1] + " (FETCH_SIZE x2 + WRITE_SIZE)"
+                    if args.spmm_k > 1 and args.k == 1:
+                        # block of vectors through the tile form: the pattern is loaded once for all columns of a pass
+                        kk = args.spmm_k
+                        Xk = mx.MultiVec(ctx, Ac.ncols, kk); Yk = mx.MultiVec(ctx, Ac.nrows, kk); Xk.random(777)
+                        for _ in range(3):
+                            Ac.apply(Xk, Yk)
+                        ctx.sync(); ctx.timer_start()
+                        nrep = max(5, args.steps // 10)
+                        for _ in range(nrep):
+                            Ac.apply(Xk, Yk)
+                        kms = ctx.timer_stop() / nrep
+                        algk = Ac.apply_bytes(kk)
+                        out[key]["spmm"] = {"block_vectors": kk, "kernel_ms": round(kms, 5),
+                                            "effective_GBps_csr_formula": round(algk / (kms * 1e-3) / 1e9, 1),
+                                            "effective_frac_of_peak": round(algk / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "bytes_moved_per_launch": int(nbytes + (Ac.nrows + Ac.ncols) * 8 * kk),
+                                            "hbm_frac_of_peak": round((nbytes + (Ac.nrows + Ac.ncols) * 8 * kk) / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                        Xk.close(); Yk.close()
                 else:
                     moved = nbytes + Ac.nrows * (2 + 8 * args.k) + Ac.ncols * 8 * args.k
                     out[key] = {"kernel": "k_spmv_cs<RgCfg<256,2048>,7>", "kernel_ms": round(cms, 5), "speedup_vs_csr": round(kern_ms / cms, 3),

@@ -4,6 +4,7 @@
 #ifndef MX_CRS_MATRIX
 #define MX_CRS_MATRIX
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -127,10 +128,10 @@ class MxCrsMatrix {
   // y = A x on the GPU; x may alias y (src/MxMagWaveOp.cpp:650,1249)
   void apply(MxMultiVector<Scalar> const& x, MxMultiVector<Scalar>& y) const {
     if (!mFilled) { std::cout << "MxCrsMatrix::apply: matrix is not fill-completed\n"; throw 1; }
-    // the compressed stream costs a host-side encoding pass (about 1 s for a 256^3 operator): operators the hot loop
-    // uses are encoded at setup (getRawMatrix), anything else once it has been applied a few times - the one-off
-    // products of the post-processing (curlCurl, curlB in checkEigensolution / magToElec) stay plain CSR
-    ensureDevice(++mApplies > 3);
+    // re-encoding costs a host-side pass over the matrix: operators the hot loop uses are encoded at setup
+    // (getRawMatrix), anything else once it has been applied a few times - the one-off products of the
+    // post-processing (curlCurl, curlB in checkEigensolution / magToElec) stay plain CSR
+    ensureDevice(mApplies.fetch_add(1) >= 3);
     MX_ABI(mxg_csr_apply(mRowMap->getComm()->getCtx(), mDev, x.raw(), y.raw()), "MxCrsMatrix::apply");
   }
 
@@ -257,7 +258,7 @@ class MxCrsMatrix {
   void ensureDevice(bool compressIt = true) const {
     static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
     if (mDev) {
-      if (compressIt && compress && !mCompressed && !ScalarTraits<Scalar>::isComplex && mRowMap->getNodeNumIndices() >= 256) {
+      if (compressIt && compress && !mCompressed && mRowMap->getNodeNumIndices() >= 256) {
         MX_ABI(mxg_csr_compress(mDev, NULL, NULL, NULL), "MxCrsMatrix (compress)");
         mCompressed = true;
       }
@@ -273,10 +274,10 @@ class MxCrsMatrix {
     MX_ABI(mxg_csr_create(mRowMap->getComm()->getCtx(), mHost.nrows, mHost.ncols - mNumGhost, mNumGhost, mHost.rowptr.data(),
                           mHost.col.data(), reinterpret_cast<const double*>(mHost.val.data()),
                           ScalarTraits<Scalar>::isComplex, halo ? &plan : NULL, &mDev), "MxCrsMatrix::fillComplete");
-    // structured operators stream 3 bytes per entry instead of 12 (mxg_csr_compress; bit-identical results);
-    // MXG_COMPRESS=0 keeps the plain CSR kernels.  With ghost columns the blocks that reference none are ordered
-    // first and overlap the halo exchange, exactly as with the CSR kernel.
-    if (compressIt && compress && !ScalarTraits<Scalar>::isComplex && mHost.nrows >= 256) {
+    // lattice operators (real or complex) take the tile form - no matrix stream for the bulk rows - other real
+    // matrices the compressed stream (mxg_csr_compress; bit-identical results); MXG_COMPRESS=0 keeps the plain CSR
+    // kernels.  With ghost columns the tiles and the rows that reference none run while the halo is in flight.
+    if (compressIt && compress && mHost.nrows >= 256) {
       MX_ABI(mxg_csr_compress_from(mDev, mHost.rowptr.data(), mHost.col.data(),
                                    reinterpret_cast<const double*>(mHost.val.data()), NULL, NULL, NULL),
              "MxCrsMatrix::fillComplete (compress)");
@@ -439,7 +440,7 @@ class MxCrsMatrix {
   mutable mx::Csr<Scalar> mHost;     // (filled on demand for a matrix formed on the device: host())
   mutable bool mHostValid = true;
   mutable bool mCompressed = false;
-  mutable int mApplies = 0;
+  mutable std::atomic<int> mApplies{0};    // applies so far (a matrix may be applied from several rank threads)
   mutable mxg_csr* mDev;
 };
 

@@ -55,6 +55,10 @@ int mxg_timer_start(mxg_ctx* ctx);
 int mxg_timer_stop(mxg_ctx* ctx, float* elapsed_ms);
 /* Comm::Barrier (src/MxMagWaveOp.cpp:71,288): stream sync + zero-byte all-reduce */
 int mxg_barrier(mxg_ctx* ctx);
+/* Measurement aid (bench.py): what a pure stream reaches on THIS device - read_bytes read once with 16-byte
+ * non-temporal loads, write_bytes written once, no gathers - averaged over `reps` passes (HIP events).  The devices
+ * of a pool differ by several per cent; the SpMV roofline fraction is reported beside this ceiling. */
+int mxg_bench_stream(mxg_ctx* ctx, int64_t read_bytes, int64_t write_bytes, int reps, float* ms_per_pass);
 
 /* In-process world: the ranks are threads of one process sharing `device` (several MxGridDomain boxes on one
  * GPU, src/MxGrid.cpp:171-193).  Same collectives as the RCCL world, staged through the host; every rank
@@ -117,15 +121,22 @@ int mxg_csr_apply(mxg_ctx* ctx, const mxg_csr* a, const mxg_mv* x, mxg_mv* y);
 /* algorithmic bytes of one apply with k columns (SURVEY section 8(d) formula):
  * nnz*(vb+4) + nrows*(8 + sb*k) + ncols*sb*k, vb = sb = 8 (real) or 16 (complex) */
 int64_t mxg_csr_apply_bytes(const mxg_csr* a, int k);
-/* tuning knob for experiments (scripts/tune_spmv.py): selects one of the SpMV kernel variants;
- * the default (row-gather kernel) is set at creation and needs no call */
+/* Which CSR kernel mxg_csr_apply runs on the plain arrays: 0 default (real: row-gather kernel with 16-bit in-block
+ * row offsets; complex: persistent LDS-DMA row-gather kernel), 1 real row-gather kernel reading the int64 row
+ * pointers of the CSR arrays, 2 complex one-block-per-workgroup stream kernel.  Any call makes a compressed form
+ * inactive again (products run on the CSR arrays) until the next mxg_csr_compress. */
 int mxg_csr_set_kernel(mxg_csr* a, int which);
-/* Opt-in re-encoding of a real matrix for mxg_csr_apply: per block of <= 256 rows the column indices
- * become 16-bit band codes and the values 8-bit indices into the block's table of distinct values
- * (3 bytes per entry instead of 12; blocks that do not fit keep plain CSR).  Same values, columns and
- * summation order: results are bit-identical to the CSR kernels.  Returns the block counts and the
- * size of the packed stream.  Used by the eigen-driver for its operators and multigrid levels; the
- * headline SpMV measurement of bench.py stays on the plain CSR arrays. */
+/* name of the kernel mxg_csr_apply launches for this matrix in its present state (for bench / profile records) */
+const char* mxg_csr_kernel_name(const mxg_csr* a);
+/* Opt-in re-encoding of a matrix for the products of the solver loops.  Lattice operators (rows that repeat along
+ * grid lines, real or complex) take the TILE form: 16-byte tile descriptors + a dictionary of wavefront-uniform
+ * patterns, irregular rows (cavity wall, line ends, rows reading ghost columns) as ELL groups of 64 rows - no matrix
+ * stream at all for the bulk.  Other real matrices take the COMPRESSED STREAM: per block of <= 256 rows the column
+ * indices become 16-bit band codes and the values 8-bit indices into the block's table of distinct values (3 bytes per
+ * entry instead of 12; blocks that do not fit keep plain CSR).  Same values, columns and summation order either way:
+ * results are bit-identical to the CSR kernels.  Returns work units (tiles + groups, or blocks), fall-back blocks and
+ * the size of the re-encoded form.  Used by the eigen-driver for its operators and multigrid levels; the headline
+ * SpMV measurement of bench.py stays on the plain CSR arrays. */
 int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes);
 /* same, encoding from the caller's host copy of the CSR arrays given to mxg_csr_create (saves reading them back) */
 /* Which product kernel a compressed matrix runs: returns 0 plain CSR, 1 compressed stream (k_spmv_cs), 3 tile patterns
@@ -134,6 +145,14 @@ int mxg_csr_compress(mxg_csr* a, int64_t* nblocks, int64_t* nfallback, int64_t* 
 int mxg_csr_product_form(const mxg_csr* a, int64_t* tiles, int64_t* patterns, int64_t* irregular_rows, double* coverage);
 int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals,
                           int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes);
+/* TEST HOOK, no GPU needed, not a product path (nothing in the library calls it): builds the tile form's host-side
+ * plan for the given CSR arrays (columns >= ncols_owned are ghosts, read from xghost) and evaluates y = A x by
+ * walking the PLAN with the kernels' arithmetic, so that the setup code can be checked against the oracle in a
+ * CPU-only container (tests/test_tile_plan.py).  stats[9] = {short tiles, long tiles, patterns, groups, ghost-free
+ * groups, long rows, rows in tiles, rows the plan missed, plan errors}.  Returns 0 when the plan is consistent. */
+int mxg_debug_tile_plan_apply(int64_t nrows, int64_t ncols_owned, const int64_t* rowptr, const int32_t* colidx,
+                              const double* vals, int is_complex, const double* x, const double* xghost, double* y,
+                              int64_t* stats);
 
 /* ------------------------------------------------------------------------------------------
  * multivector  (replaces Epetra_MultiVector behind MxMultiVector / MxAnasaziMV,

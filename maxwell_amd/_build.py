@@ -18,7 +18,7 @@ LIBDIR = os.path.join(ROOT, "maxwell_amd", "lib")
 INCLUDE = os.path.join(ROOT, "include")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
-DEVICE_SOURCES = ["mxg_ctx.hip", "mxg_comm.hip", "mxg_mv.hip", "mxg_csr.hip", "mxg_pat.hip", "mxg_spalg.hip", "mxg_solve.hip"]
+DEVICE_SOURCES = ["mxg_ctx.hip", "mxg_comm.hip", "mxg_mv.hip", "mxg_csr.hip", "mxg_tile.hip", "mxg_spalg.hip", "mxg_solve.hip"]
 HOST_SOURCES = ["mx_geometry.cpp", "mx_yee.cpp", "mxh_sim.cpp", "mxh_mg.cpp", "mxh_solver.cpp",
                 "mxh_problem.cpp", "mxh_io.cpp"]
 CLI_SOURCE = "maxwell.cpp"          # the reference's `maxwell --infile=deck.mx` entry point

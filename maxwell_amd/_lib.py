@@ -71,6 +71,9 @@ MXG_SIGNATURES = {
     "mxg_csr_compress": (C.c_int, [vp, c_i64p, c_i64p, c_i64p]),
     "mxg_csr_compress_from": (C.c_int, [vp, vp, vp, vp, c_i64p, c_i64p, c_i64p]),
     "mxg_csr_set_kernel": (C.c_int, [vp, C.c_int]),
+    "mxg_csr_kernel_name": (C.c_char_p, [vp]),
+    "mxg_bench_stream": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
+    "mxg_debug_tile_plan_apply": (C.c_int, [C.c_int64, C.c_int64, vp, vp, vp, C.c_int, vp, vp, vp, c_i64p]),
     "mxg_mv_create": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.POINTER(vp)]),
     "mxg_mv_view": (C.c_int, [vp, c_ip, C.c_int, C.POINTER(vp)]),
     "mxg_mv_clone": (C.c_int, [vp, c_ip, C.c_int, C.POINTER(vp)]),

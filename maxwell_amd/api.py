@@ -105,6 +105,12 @@ class Ctx:
     def barrier(self):
         _chk(self.lib.mxg_barrier(self.h), self.lib)
 
+    def stream_ceiling_ms(self, read_bytes, write_bytes, reps=20):
+        """ms per pass of a pure stream with this byte mix on this device (mxg_bench_stream)."""
+        ms = C.c_float()
+        _chk(self.lib.mxg_bench_stream(self.h, int(read_bytes), int(write_bytes), reps, C.byref(ms)), self.lib)
+        return ms.value
+
     def timer_start(self):
         _chk(self.lib.mxg_timer_start(self.h), self.lib)
 
@@ -334,10 +340,15 @@ class CsrMatrix:
         return self.lib.mxg_csr_apply_bytes(self.h, k)
 
     def set_kernel(self, which):
-        self.lib.mxg_csr_set_kernel(self.h, which)
+        """0 default CSR kernels, 1 row-gather kernel on the int64 row pointers, 2 complex stream kernel (mxg.h)."""
+        _chk(self.lib.mxg_csr_set_kernel(self.h, which), self.lib)
+
+    def kernel_name(self):
+        return (self.lib.mxg_csr_kernel_name(self.h) or b"").decode()
 
     def compress(self):
-        """Re-encode for the compressed-stream kernel; returns (blocks, fallback blocks, stream bytes)."""
+        """Re-encode for the solver's product kernels (tile form or compressed stream, mxg.h); returns (work units,
+        fallback blocks, bytes of the re-encoded form)."""
         nb, nf, sb = C.c_int64(), C.c_int64(), C.c_int64()
         _chk(self.lib.mxg_csr_compress(self.h, C.byref(nb), C.byref(nf), C.byref(sb)), self.lib)
         return nb.value, nf.value, sb.value

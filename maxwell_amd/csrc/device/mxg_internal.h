@@ -138,15 +138,6 @@ struct mxg_csr {
   void* d_csdesc = nullptr;
   unsigned char* d_csstream = nullptr;
   int64_t ncs = 0, cs_fallback = 0, cs_bytes = 0;
-  int cs_patterned = -1;         // records built with (1) / without (0) pattern tables
-  // pattern-dictionary product (mxg_pat.hip): per-row dictionary ids, the dictionary, the individual rows
-  unsigned short* d_rowpid = nullptr;
-  void* d_patdict = nullptr;
-  int32_t* d_grows = nullptr;
-  int64_t pat_npat = 0, pat_ngrows = 0, pat_gnnz = 0;
-  unsigned short* d_pairid = nullptr;   // row-pair form of the pattern product (mxg_pat.hip): id per pair of rows
-  void* d_pairdict = nullptr;
-  int64_t pat_npair = 0;
   // injection form (every row has at most one entry: the piecewise-constant prolongations of the multigrid): built on
   // the first product with the coarse-correction epilogue; inj_state 0 unknown, 1 in use, -1 not an injection
   int inj_state = 0;
@@ -163,18 +154,21 @@ struct mxg_csr {
   // (row blocks, diagonal, pipeline descriptors) only when something applies / compresses it: the intermediates of the
   // operator chain never do (mxg_csr_materialize)
   int lazy = 0;
-  void* d_tiledesc = nullptr;           // tile form of the pattern product (mxg_pat.hip, MXG_PAT=3): 16-byte tile descriptors,
-  void* d_tiledict = nullptr;           // wavefront-uniform tile patterns; irregular rows in d_grows
-  int64_t pat_ntile = 0, pat_ntilepat = 0;
+  // tile form (mxg_tile.hip): wavefront-uniform tiles of short (A: <= 8 entries) and long (B: 9..16) patterns, the
+  // irregular rows as ELL groups of 64 rows (ghost-free groups first) and rows of more than 40 entries as "long rows"
+  int tile_on = 0, tile_tried = 0;      // tile_tried: mxg_tile_build has looked at this matrix (it may have declined: coverage)
+  void* d_tiledescA = nullptr; void* d_tiledictA = nullptr;
+  void* d_tiledescB = nullptr; void* d_tiledictB = nullptr;
+  int64_t tile_ntA = 0, tile_ntB = 0;
+  int32_t* d_grow = nullptr;            // row ids, 64 per group (-1 padding)
+  void* d_ggrp = nullptr;               // 16-byte group descriptors
+  int32_t* d_gcol = nullptr;            // [group][width][64]
+  double* d_gval = nullptr;
+  int32_t* d_lrows = nullptr;
+  int64_t gen_ngrp = 0, gen_ngrp_interior = 0, gen_nlong = 0, gen_nlong_interior = 0;
+  int64_t pat_ntile = 0, pat_ntilepat = 0, pat_ngrows = 0, tile_bytes = 0;
   double pat_tile_coverage = 0.0;       // fraction of the rows inside tiles
-  int64_t cs_pattern_rows = 0;   // rows encoded as one pattern id (persistent kernel's records)
   int64_t ncs_interior = 0;      // compressed descriptors [0, ncs_interior) reference no ghost column
-  // x-window kernel: 96-byte block descriptors + 16-bit block-local column ids
-  void* d_xwdesc = nullptr;
-  unsigned short* d_lcol = nullptr;
-  int64_t nxw = 0;
-  int64_t xw_unstaged = 0;
-  int xw_geo = -1;
   // diagonal (for Jacobi) extracted at creation
   double* d_diag = nullptr;
   // halo
@@ -222,14 +216,13 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
                           const double* diag, double omega, double beta = 0.0);
 int mxg_dev_csr_apply_dot(mxg_ctx* ctx, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out);
 
-// pattern-dictionary product (mxg_pat.hip)
-int mxg_pat_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
-int mxg_pair_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
+// tile product (mxg_tile.hip)
 int mxg_tile_build(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals);
-int64_t mxg_pat_partials(const mxg_csr* a);
-int mxg_pat_launch(mxg_ctx* c, mxg_csr* a, const double* x, double* y, int epi, int dot, const double* xdot,
-                   double* partial, const double* rhs, const double* diag, double omega, double beta, int halo,
-                   const double* xg);
+void mxg_tile_free(mxg_csr* a);
+int64_t mxg_tile_partials(const mxg_csr* a);
+int mxg_tile_launch(mxg_ctx* c, mxg_csr* a, const double* x, long long ldx, double* y, long long ldy, int k, int epi,
+                    int dot, const double* xdot, double* partial, const double* rhs, const double* diag, double omega,
+                    double beta, int halo, const double* xg, long long ldg);
 
 inline int mxg_grid_for(int64_t n, int block, int per_thread, int cap) {
   int64_t g = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);

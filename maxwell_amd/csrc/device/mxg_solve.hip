@@ -522,7 +522,7 @@ int prec_view(mxg_ctx* c, const mxg_csr* A, const mxg_solve_opts* o, mxg_mv* v, 
 
 bool cg_fused_ok(const mxg_csr* A, const mxg_solve_opts* o) {
   // (must not depend on how many rows THIS rank owns: every rank of a decomposed grid has to take the same path)
-  return !A->is_complex && A->pipe_geo == 10 && (A->kernel & 0x30000) &&
+  return !A->is_complex && A->pipe_geo == 10 &&
          (o->precond <= 1 || (o->precond == 3 && o->mg != nullptr));
 }
 

@@ -1,5 +1,7 @@
 """K1: CSR SpMV / SpMM through the C ABI against the serial row loop of the oracle -- bit exact
 (products are rounded, then added in storage order on both sides)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -52,11 +54,10 @@ def test_spmm_block_of_vectors(ctx, oracle_pillbox12, rng, k):
     assert np.array_equal(_apply(ctx, m, x), cref.spmv(m, x))
 
 
-@pytest.mark.parametrize("code", [0x2750000, 0x750000])
+@pytest.mark.parametrize("code", [0, 1])
 def test_spmm_views_every_row_gather_kernel(ctx, oracle_pillbox16, rng, code):
-    """Blocks of vectors and views of scattered columns through the persistent (LDS-DMA, double-buffered) and the
-    one-block-per-workgroup row-gather kernels; many more row blocks than workgroup slots per XCD would need
-    a bigger matrix - tests/test_fullsize_gpu.py covers that."""
+    """Blocks of vectors and views of scattered columns through the row-gather kernel with 16-bit in-block row offsets
+    (0, the default) and with the int64 row pointers of the CSR arrays (1)."""
     _, o = oracle_pillbox16
     m = o["curlCurl"]
     x = rng.uniform(-1, 1, (m.shape[1], 6))
@@ -104,11 +105,11 @@ def test_views_of_noncontiguous_columns(ctx, oracle_pillbox12, rng):
     assert np.array_equal(got[:, [1, 3, 0]], want) and np.all(got[:, [2, 4]] == 0)
 
 
-@pytest.mark.parametrize("code", [None, 0x0])
+@pytest.mark.parametrize("code", [None, 2])
 def test_complex_matrix(ctx, rng, code):
     """Complex scalars are interleaved pairs (the reference's 2x2 real embedding,
     src/MxCrsMatrix.cpp:146-170, collapses to complex multiply-add).  Default: the persistent row-gather kernel
-    over 16-byte values; code 0: the one-block-per-workgroup stream kernel.  Includes an over-long row, empty rows
+    over 16-byte values; code 2: the one-block-per-workgroup stream kernel.  Includes an over-long row, empty rows
     and views of scattered columns."""
     n = 3000
     m = (sp.random(n, n, density=4.0 / n, random_state=7, format="csr")
@@ -196,11 +197,10 @@ def test_full_size_linearity_and_constant_nullspace(ctx):
     assert p.norm2()[0] < 1e-9 * b.norm2()[0]
 
 
-@pytest.mark.parametrize("code", [0x2750000, 0x6750000, 0x2450000, 0x2050000, 0x10000, 0x20000, 0x710000, 0x750000, 0x460000, 0x410000, 0x4000, 0x8000, 0x0, 0x2, 0x4, 0x10, 0x20, 0x30, 0x540, 0x840, 0x480, 0x180, 0x1])
+@pytest.mark.parametrize("code", [0, 1])
 def test_every_kernel_variant_bit_exact(ctx, oracle_pillbox16, rng, code):
-    """All tuning variants (plain / non-temporal loads, XCD remap, block geometries, the
-    software-pipelined persistent kernel) must give the same bits as the serial row loop;
-    the lane-group kernel (code 1) reduces with shuffles and is only rounding-close."""
+    """The shipped CSR kernels of a real matrix (16-bit row offsets / int64 row pointers) give the bits of the serial
+    row loop; an unknown code is an error, not a silent default."""
     _, o = oracle_pillbox16
     m = yee.shifted(o["vecLapl"], o["mRhs"], 1.9739208802178716)
     x = rng.uniform(-1, 1, m.shape[1])
@@ -209,15 +209,13 @@ def test_every_kernel_variant_bit_exact(ctx, oracle_pillbox16, rng, code):
     X = mx.MultiVec.from_numpy(ctx, x)
     Y = mx.MultiVec(ctx, m.shape[0], 1)
     A.apply(X, Y)
-    got, want = Y.to_numpy()[:, 0], cref.spmv(m, x)
-    if code == 1:
-        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
-    else:
-        assert np.array_equal(got, want)
+    assert np.array_equal(Y.to_numpy()[:, 0], cref.spmv(m, x))
+    with pytest.raises(mx.MxError, match="unknown kernel code"):
+        A.set_kernel(0x750000)
 
 
-def test_pipelined_kernel_ragged(ctx, rng):
-    """Pipelined kernel on ragged rows incl. empty stretches and an over-long row."""
+def test_row_gather_kernel_ragged(ctx, rng):
+    """Row-gather kernels on ragged rows incl. empty stretches and an over-long row."""
     n = 6000
     rows = [rng.choice(n, size=int(c), replace=False) for c in rng.integers(0, 25, size=n)]
     rows[3] = np.arange(n)[:3000]
@@ -228,7 +226,7 @@ def test_pipelined_kernel_ragged(ctx, rng):
     m = sp.csr_matrix((rng.uniform(-1, 1, len(indices)), indices, indptr), shape=(n, n))
     x = rng.uniform(-1, 1, n)
     want = cref.spmv(m, x)
-    for code in (0x2750000, 0x6750000, 0x10000, 0x20000, 0x4000, 0x8000, 0x540, 0x480):
+    for code in (0, 1):
         A = mx.CsrMatrix.from_scipy(ctx, m)
         A.set_kernel(code)
         X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, n, 1)
@@ -276,24 +274,36 @@ def test_halo_exchange_on_a_one_rank_communicator(built, oracle_pillbox12, rng):
             X2 = mx.MultiVec.from_numpy(ctx1, x2); Y2 = mx.MultiVec(ctx1, n, 1)
             A.apply(X2, Y2)
             assert np.array_equal(Y2.to_numpy(), cref.spmv(m, x2))
-        # kernels without the interior/boundary split assemble [owned | ghosts] (stream kernel), then back
-        A.set_kernel(0x0)
+        # the int64-row-pointer variant of the kernel, then back; x aliasing y takes the [owned | ghosts] copy
+        A.set_kernel(1)
         A.apply(X, Y)
         assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
-        A.set_kernel(0x750000)
+        A.set_kernel(0)
         A.apply(X, Y)
         assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
-        # compressed stream on the ghosted matrix: interior blocks first, boundary blocks read the ghost buffer after
-        # the exchange (k_spmv_cs<..., HALO>), over real ncclSend/ncclRecv; two columns take the packed-x route
-        nb, nfall, _ = A.compress()
-        assert nb > 0
-        for rep in range(2):
-            x3 = rng.uniform(-1, 1, (n, 1))
-            X3 = mx.MultiVec.from_numpy(ctx1, x3); Y3 = mx.MultiVec(ctx1, n, 1)
-            A.apply(X3, Y3)
-            assert np.array_equal(Y3.to_numpy(), cref.spmv(m, x3))
-        A.apply(X, Y)
-        assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+        Z = mx.MultiVec.from_numpy(ctx1, x)
+        A.apply(Z, Z)
+        assert np.array_equal(Z.to_numpy(), cref.spmv(m, x))
+        # compressed forms on the ghosted matrix, over real ncclSend/ncclRecv.  Compressed stream (MXG_PAT=0): interior
+        # blocks first, boundary blocks read the ghost buffer after the exchange (k_spmv_cs<..., HALO>).  Tile form
+        # (forced: coverage threshold 0): tiles and ghost-free groups first, ghost-reading groups behind the halo event,
+        # two columns in one pass.
+        for pat, cov, form in (("0", None, 1), ("1", "0", 3)):
+            os.environ["MXG_PAT"] = pat
+            if cov is not None:
+                os.environ["MXG_TILE_MIN_COVERAGE"] = cov
+            try:
+                nb, nfall, _ = A.compress()
+            finally:
+                os.environ.pop("MXG_PAT", None); os.environ.pop("MXG_TILE_MIN_COVERAGE", None)
+            assert nb > 0 and A.product_form()[0] == form
+            for rep in range(2):
+                x3 = rng.uniform(-1, 1, (n, 1))
+                X3 = mx.MultiVec.from_numpy(ctx1, x3); Y3 = mx.MultiVec(ctx1, n, 1)
+                A.apply(X3, Y3)
+                assert np.array_equal(Y3.to_numpy(), cref.spmv(m, x3))
+            A.apply(X, Y)
+            assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
         # fused CG (SpMV + dot with the halo in flight) on the ghosted matrix
         spd = (m + m.T).tocsr() * 0.5 + sp.identity(n) * 40.0
         cols2 = spd.indices.astype(np.int64).copy()
@@ -308,10 +318,17 @@ def test_halo_exchange_on_a_one_rank_communicator(built, oracle_pillbox12, rng):
         Bv = mx.MultiVec.from_numpy(ctx1, bvec); Xs = mx.MultiVec(ctx1, n, 1); Xs.fill(0.0)
         it, conv, res = S.solve(Bv, Xs, method="cg", tol=1e-10, precond="jacobi")
         assert conv and np.linalg.norm(spd @ Xs.to_numpy()[:, 0] - bvec) < 1e-8
-        S.compress()                       # the same solve from the compressed stream (fused p.Ap with ghosts)
-        Xs.fill(0.0)
-        it2, conv2, _ = S.solve(Bv, Xs, method="cg", tol=1e-10, precond="jacobi")
-        assert conv2 and abs(it2 - it) <= 2 and np.linalg.norm(spd @ Xs.to_numpy()[:, 0] - bvec) < 1e-8
+        for pat, cov in (("0", None), ("1", "0")):   # the same solve from the compressed stream / the tile form (fused p.Ap with ghosts)
+            os.environ["MXG_PAT"] = pat
+            if cov is not None:
+                os.environ["MXG_TILE_MIN_COVERAGE"] = cov
+            try:
+                S.compress()
+            finally:
+                os.environ.pop("MXG_PAT", None); os.environ.pop("MXG_TILE_MIN_COVERAGE", None)
+            Xs.fill(0.0)
+            it2, conv2, _ = S.solve(Bv, Xs, method="cg", tol=1e-10, precond="jacobi")
+            assert conv2 and abs(it2 - it) <= 2 and np.linalg.norm(spd @ Xs.to_numpy()[:, 0] - bvec) < 1e-8
         S.close()
         # the collectives of C2 on the same communicator
         assert np.abs(X.norm2() - np.linalg.norm(x, axis=0)).max() < 1e-12
@@ -340,9 +357,9 @@ def test_config3_cylinder_and_config5_sphere_geometries(ctx, rng):
             assert np.array_equal(Y.to_numpy(), cref.spmv(host, x))
 
 
-# (MXG_PAT, MXG_CSP) at compress time, then launch-time switches of the pattern kernels
-CS_MODES = {"tile": ("3", "0", {"MXG_TILE_MIN_COVERAGE": "0"}), "pair": ("2", "0", {}), "pair4": ("2", "0", {"MXG_PAIR_U": "4"}), "pairw": ("2", "0", {"MXG_PAIRW": "1"}),
-            "pat": ("1", "0", {}), "patrow": ("1", "0", {"MXG_PATW": "0"}), "cs": ("0", "0", {}), "csp": ("0", "1", {}), "default": (None, "0", {})}
+# MXG_PAT at compress time: "tile" forces the tile form (coverage threshold 0), "cs" the compressed stream, "default"
+# lets mxg_csr_compress choose (tile form where the tiles cover >= 80 % of the rows)
+CS_MODES = {"tile": ("1", {"MXG_TILE_MIN_COVERAGE": "0"}), "cs": ("0", {}), "default": (None, {})}
 
 
 def _cs_env(monkeypatch, mode):
@@ -350,22 +367,17 @@ def _cs_env(monkeypatch, mode):
         monkeypatch.delenv("MXG_PAT", raising=False)
     else:
         monkeypatch.setenv("MXG_PAT", CS_MODES[mode][0])
-    monkeypatch.setenv("MXG_CSP", CS_MODES[mode][1])
-    for k in ("MXG_PAIR_U", "MXG_PAIRW", "MXG_PATW", "MXG_TILE_MIN_COVERAGE"):
-        monkeypatch.delenv(k, raising=False)
-    for k, v in CS_MODES[mode][2].items():
+    monkeypatch.delenv("MXG_TILE_MIN_COVERAGE", raising=False)
+    for k, v in CS_MODES[mode][1].items():
         monkeypatch.setenv(k, v)
 
 
 @pytest.mark.parametrize("mode", list(CS_MODES))
 def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, mode, monkeypatch):
-    """mxg_csr_compress: 16-bit band codes + 8-bit value-table indices per row block; every operator of
-    the pillbox (bulk blocks pack, cut-cell blocks fall back to plain CSR rows), SpMV and SpMM, and the
-    fused SpMV+dot of CG give the same bits as the serial row loop.  Modes: "tile" wavefront-uniform tile patterns through
-    scalar loads, irregular rows in the same launch (k_spmv_tile); "pair" / "pair4" the row-pair pattern product
-    (k_spmv_pair with 2 / 4 pairs per lane + k_spmv_gen), "pairw" its wave-persistent form, "pat" the pattern-dictionary
-    product (k_spmv_patw + k_spmv_gen), "patrow" one thread per row (k_spmv_pat), "cs" one record per workgroup (k_spmv_cs, the default), "csp" the persistent record
-    kernel with a loader wave (k_spmv_csp)."""
+    """mxg_csr_compress: every operator of the pillbox, SpMV and SpMM, and the fused SpMV+dot of CG give the same bits as
+    the serial row loop.  Modes: "tile" wavefront-uniform tile patterns through scalar loads, irregular rows as ELL groups
+    in the same launch, all columns of a block of vectors in one pass (k_spmv_tile); "cs" 16-bit band codes + 8-bit
+    value-table indices per row block (k_spmv_cs: bulk blocks pack, cut-cell blocks fall back to plain CSR rows)."""
     _cs_env(monkeypatch, mode)
     _, o = oracle_pillbox16
     packed_any = False
@@ -375,7 +387,7 @@ def test_compressed_stream_bit_identical(ctx, oracle_pillbox16, rng, mode, monke
         nb, nf, nbytes = A.compress()
         assert nb > 0 and 0 <= nf <= nb
         packed_any = packed_any or nf < nb
-        for k in (1, 3):
+        for k in (1, 3, 8):
             x = rng.uniform(-1, 1, (m.shape[1], k))
             X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, m.shape[0], k)
             A.apply(X, Y)
@@ -431,3 +443,75 @@ def test_compressed_stream_fallbacks(ctx, rng, mode, monkeypatch):
     mask = np.ones(n, bool); mask[5] = False
     assert np.array_equal(got[mask], want[mask])
     assert abs(got[5] - want[5]) <= 1e-12 * np.abs(m[5].data).sum()
+
+
+def test_tile_form_complex_operator(ctx, rng, monkeypatch):
+    """Complex lattice operator (Bloch phases across the periodic seams): tiles carry (re, im) value lists, one row per
+    lane; blocks of vectors and scattered views; bit-identical to the complex row loop of the oracle."""
+    monkeypatch.setenv("MXG_TILE_MIN_COVERAGE", "0")
+    s = yee.YeeSim(12, strict=False, phase_shifts=(0.3, 0.0, 0.7))
+    o = s.wave_ops()
+    m = yee.shifted(o["vecLapl"], o["mRhs"], 0.5).tocsr().astype(np.complex128)
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    nb, nf, _ = A.compress()
+    form, tiles, pats, irregular, cov = A.product_form()
+    assert form == 3 and tiles > 0 and cov > 0.2
+    x = rng.uniform(-1, 1, (m.shape[1], 5)) + 1j * rng.uniform(-1, 1, (m.shape[1], 5))
+    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, m.shape[0], 5, True)
+    A.apply(X, Y)
+    assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+    Y.fill(0.0)
+    A.apply(X.view([4, 0, 2]), Y.view([1, 3, 0]))
+    got = Y.to_numpy()
+    assert np.array_equal(got[:, [1, 3, 0]], cref.spmv(m, x[:, [4, 0, 2]])) and np.all(got[:, [2, 4]] == 0)
+    A.apply(X, X)                                        # aliasing: works from a copy of x
+    assert np.array_equal(X.to_numpy(), cref.spmv(m, x))
+
+
+def test_tile_form_long_patterns_and_wide_groups(ctx, rng, monkeypatch):
+    """A one-component 13-point stencil: long-pattern tiles (9..16 entries, one tile per wavefront); rows of 33..40
+    entries are ELL group rows, rows of more entries long rows; SpMV, SpMM and the fused epilogues."""
+    monkeypatch.setenv("MXG_TILE_MIN_COVERAGE", "0")
+    n = 6000
+    offs = np.array([-900, -600, -300, -30, -20, -10, 0, 10, 20, 30, 300, 600, 900])
+    vals = rng.uniform(-1, 1, 13)
+    rows, cols, data = [], [], []
+    for r in range(n):
+        if 1000 <= r < 4000:
+            rows += [r] * 13; cols += list(r + offs); data += list(vals)
+        elif r % 7 == 0:
+            c = np.sort(rng.choice(n, size=int(rng.integers(30, 48)), replace=False))
+            rows += [r] * len(c); cols += list(c); data += list(rng.uniform(-1, 1, len(c)))
+        else:
+            rows += [r]; cols += [r]; data += [2.0]
+    m = sp.csr_matrix((data, (rows, cols)), shape=(n, n)); m.sort_indices()
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    A.compress()
+    assert A.product_form()[0] == 3
+    x = rng.uniform(-1, 1, (n, 4))
+    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, n, 4)
+    A.apply(X, Y)
+    assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
+
+
+def test_recompress_after_switching_the_form(ctx, oracle_pillbox16, rng, monkeypatch):
+    """mxg_csr_compress follows MXG_PAT at the time of the call: tile form -> compressed stream -> tile form on one
+    matrix, and mxg_csr_set_kernel returns to the CSR kernels in between (a stale form must never be
+    launched with an empty grid)."""
+    _, o = oracle_pillbox16
+    m = yee.shifted(o["vecLapl"], o["mRhs"], 1.97).tocsr()
+    x = rng.uniform(-1, 1, m.shape[1])
+    want = cref.spmv(m, x)
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, m.shape[0], 1)
+    monkeypatch.setenv("MXG_TILE_MIN_COVERAGE", "0")
+    for pat, form in (("1", 3), ("0", 1), ("1", 3)):
+        monkeypatch.setenv("MXG_PAT", pat)
+        A.compress()
+        assert A.product_form()[0] == form
+        Y.fill(0.0); A.apply(X, Y)
+        assert np.array_equal(Y.to_numpy()[:, 0], want)
+        A.set_kernel(0)
+        assert A.product_form()[0] == 0
+        Y.fill(0.0); A.apply(X, Y)
+        assert np.array_equal(Y.to_numpy()[:, 0], want)
