@@ -1185,6 +1185,7 @@ extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const in
     // the tile form first: a lattice operator needs no compressed stream at all - its encoding pass (0.6 s for a
     // 256^3 operator) and 0.5 GB of device memory are saved
     mxg_tile_free(a);
+    a->tile_tried = 0;
     if (want_tile) { MXG_TRY(mxg_tile_build(a, rowptr, colidx, vals)); a->tile_tried = 1; }
     if (!a->tile_on && !a->is_complex && a->ncs == 0) MXG_TRY(build_cs(a, rowptr, colidx, vals));
   }

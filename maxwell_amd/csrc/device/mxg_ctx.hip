@@ -191,16 +191,23 @@ namespace {
 typedef double dbl2s __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_stream_ceiling(const dbl2s* __restrict__ src, long long n16, dbl2s* __restrict__ dst,
                                                          long long m16, double* __restrict__ sink) {
-  const long long stride = (long long)gridDim.x * 256;
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  // every workgroup owns one contiguous chunk, XCD w % 8 a contiguous eighth (the mapping of the SpMV kernels); four
+  // 16-byte non-temporal loads in flight per thread.  Of the shapes tried (grid-stride / chunked, plain / non-temporal,
+  // 4 / 8 loads in flight, 4 / 8 / 16 workgroups per CU: scripts/exp_tile.hip) this one reads fastest: 6.0 TB/s.
+  const long long nb = gridDim.x, per = (nb + 7) / 8, b = (blockIdx.x % 8) * per + blockIdx.x / 8;
   dbl2s acc; acc.x = 0.0; acc.y = 0.0;
-  for (; i + 3 * stride < n16; i += 4 * stride) {            // four 16-byte loads in flight per thread
-    const dbl2s a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-    const dbl2s c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-    acc += a; acc += b; acc += c; acc += d;
+  if (b < nb) {
+    const long long c0 = n16 * b / nb, c1 = n16 * (b + 1) / nb;
+    for (long long i = c0 + threadIdx.x; i < c1; i += 256 * 4) {
+      dbl2s t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const long long q = i + 256 * u; t[u] = q < c1 ? __builtin_nontemporal_load(src + q) : acc * 0.0; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += t[u];
+    }
+    const long long w0 = m16 * b / nb, w1 = m16 * (b + 1) / nb;
+    for (long long j = w0 + threadIdx.x; j < w1; j += 256) __builtin_nontemporal_store(acc, dst + j);
   }
-  for (; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i);
-  for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < m16; j += stride) __builtin_nontemporal_store(acc, dst + j);
   if (acc.x == 1.2345e300) sink[0] = acc.y;                   // keeps the loads alive
 }
 }  // namespace

@@ -35,6 +35,7 @@ namespace {
 constexpr int TL_SHORT = 8, TL_LONG = 16;      // entries of a short / long pattern
 constexpr int TILE_ROWS = 126, TILE_ROWS_C = 63, TILE_WAVES = 4, TILE_MIN_RUN = 24, TILE_TPW = 2;
 constexpr int TILE_BLOCK = 64 * TILE_WAVES;
+constexpr int TILE_ORDER = 2;                  // placement of the group octets in the grid (k_spmv_tile): spread, 0.116 against 0.122 ms first / last at 256^3
 constexpr int GEN_MAXW = 40;                   // widest ELL group (35: dielectric interface rows of the FIT stencil); longer rows are "long rows"
 
 typedef double dbl2p __attribute__((ext_vector_type(2)));
@@ -65,15 +66,18 @@ static_assert(sizeof(TileEntryC) == 1024, "complex tile dictionary entry layout"
 struct GenGroup { long long off; int width, pad; };                  // off: first slot of the group in gcol / gval (64 per entry slot)
 static_assert(sizeof(GenGroup) == 16, "group descriptor layout");
 
-// everything a launch needs, passed by value
+// What a launch needs beyond its pointer parameters, passed by value.  The descriptors and dictionaries a wavefront
+// reads with scalar loads are separate `const T* __restrict__` kernel parameters: the compiler only emits s_load for
+// memory it can prove read-only, which it cannot for pointers that arrive inside a struct (measured: the tile rows ran
+// 2.3 x slower with every pattern value fetched by a vector load).
 struct TileArgs {
-  const TileDesc* descA; const void* dictA; long long ntA, ntbA;     // short-pattern tiles, their workgroups
-  const TileDesc* descB; const void* dictB; long long ntB, ntbB;     // long-pattern tiles
-  const GenGroup* ggrp; const int* grow; const int* gcol; const double* gval; long long ng0, ngn;   // groups [ng0, ng0 + ngn)
+  long long ntA, ntbA;                                                // short-pattern tiles, their workgroups
+  long long ntB, ntbB;                                                // long-pattern tiles
+  const int* grow; const int* gcol; const double* gval; long long ng0, ngn;   // groups [ng0, ng0 + ngn)
   const int* lrows; long long nl0, nln;                               // long rows [nl0, nl0 + nln)
   const long long* rowptr; const int* colidx; const double* vals;
-  long long ngbG, ngbL, ngb;                                          // workgroups of groups / long rows / both rounded up to 8
-  const double* x; long long ldx; double* y; long long ldy; int k;
+  long long ngbG, ngbL, ngb;                                          // workgroups of groups / long rows; ngb = each rounded up to 8, summed
+  long long ldx, ldy; int order;                                      // order: placement of the group octets (kernel comment)
   const double* xdot; double* partial; const double* rhs; const double* diag; double omega, beta;
   const double* xg; long long ldg; long long nowned;
 };
@@ -122,7 +126,8 @@ __device__ inline void tile_block_sum(double part, double* __restrict__ partial,
 // ---- real tiles: two rows per lane, pattern in SGPRs ---------------------------------------------------------------
 template <typename ENTRY, int NL, int TPW, bool DOT, int EPI>
 __device__ inline void tile_rows_real(const TileDesc* __restrict__ desc, const ENTRY* __restrict__ dict, long long ntiles,
-                                      long long ntb, long long tile_block, const TileArgs& A, double& part) {
+                                      long long ntb, long long tile_block, const double* __restrict__ x, double* __restrict__ y,
+                                      const TileArgs& A, double& part) {
   const long long tb = tile_xcd_block(tile_block, ntb);            // XCD w % 8 walks a contiguous eighth of the tiles
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const long long t0 = (tb * TILE_WAVES + wave) * TPW;             // TPW consecutive tiles per wavefront
@@ -140,86 +145,84 @@ __device__ inline void tile_rows_real(const TileDesc* __restrict__ desc, const E
     len[u] = e[u]->len;
     on[u] = t0 + u < ntiles && 2 * lane < d[u].nrows;              // nrows is even
   }
-  for (int j = 0; j < A.k; ++j) {                                  // the pattern serves every column of the block of vectors
-    const double* __restrict__ x = A.x + j * A.ldx;
-    double* __restrict__ y = A.y + j * A.ldy;
-    dbl2p xv[TPW][NL];
+  dbl2p xv[TPW][NL];
 #pragma unroll
-    for (int u = 0; u < TPW; ++u)
-      if (on[u]) {
+  for (int u = 0; u < TPW; ++u)
+    if (on[u]) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
-          if (i < len[u]) {                                        // uniform
-            const double* xp = x + ((long long)d[u].start + e[u]->delta[i]);   // scalar base
-            const dbl2u tt = *reinterpret_cast<const dbl2u*>(xp + 2 * lane);
-            xv[u][i].x = tt.x; xv[u][i].y = tt.y;
-          }
-      }
+      for (int i = 0; i < NL; ++i)
+        if (i < len[u]) {                                          // uniform
+          const double* xp = x + ((long long)d[u].start + e[u]->delta[i]);   // scalar base
+          const dbl2u tt = *reinterpret_cast<const dbl2u*>(xp + 2 * lane);
+          xv[u][i].x = tt.x; xv[u][i].y = tt.y;
+        }
+    }
 #pragma unroll
-    for (int u = 0; u < TPW; ++u)
-      if (on[u]) {
-        const long long row = (long long)d[u].start + 2 * lane;
-        dbl2p sum; sum.x = 0.0; sum.y = 0.0;
+  for (int u = 0; u < TPW; ++u)
+    if (on[u]) {
+      const long long row = (long long)d[u].start + 2 * lane;
+      dbl2p sum; sum.x = 0.0; sum.y = 0.0;
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
-          if (i < len[u]) {
-            const double v0 = e[u]->v[0][i], v1 = e[u]->v[1][i], v2 = e[u]->v[2][i];
-            const double va = ca == 0 ? v0 : (ca == 1 ? v1 : v2), vb = cb == 0 ? v0 : (cb == 1 ? v1 : v2);
-            sum.x = sum.x + va * xv[u][i].x;
-            sum.y = sum.y + vb * xv[u][i].y;
-          }
-        dbl2p o;
-        if (EPI == 0) {
-          o = sum;
-        } else {
-          dbl2p rr, dg, xr, yy;
-          if (EPI != 3) { const dbl2u q = *reinterpret_cast<const dbl2u*>(A.rhs + row); rr.x = q.x; rr.y = q.y; }
-          if (EPI == 1 || EPI == 4 || EPI == 5) {
-            const dbl2u q2 = *reinterpret_cast<const dbl2u*>(x + row);
-            xr.x = q2.x; xr.y = q2.y;
-            const int ds = e[u]->dslot;                            // uniform
-            if (ds >= 0) {                                         // the diagonal is an entry of the pattern: no load
-              const double d0 = e[u]->v[0][ds], d1 = e[u]->v[1][ds], d2 = e[u]->v[2][ds];
-              dg.x = ca == 0 ? d0 : (ca == 1 ? d1 : d2);
-              dg.y = cb == 0 ? d0 : (cb == 1 ? d1 : d2);
-            } else {
-              const dbl2u q1 = *reinterpret_cast<const dbl2u*>(A.diag + row);
-              dg.x = q1.x; dg.y = q1.y;
-            }
-          }
-          if (EPI == 3 || EPI == 4) { const dbl2u q = *reinterpret_cast<const dbl2u*>(y + row); yy.x = q.x; yy.y = q.y; }
-          const double omega = A.omega, beta = A.beta;
-          if (EPI == 2) { o.x = rr.x - sum.x; o.y = rr.y - sum.y; }
-          else if (EPI == 3) { o.x = yy.x + omega * sum.x; o.y = yy.y + omega * sum.y; }
-          else if (EPI == 1) {
-            o.x = dg.x != 0.0 ? xr.x + omega * (rr.x - sum.x) / dg.x : xr.x;
-            o.y = dg.y != 0.0 ? xr.y + omega * (rr.y - sum.y) / dg.y : xr.y;
-          } else if (EPI == 5) {
-            o.x = dg.x != 0.0 ? xr.x + beta * xr.x + omega * (rr.x - sum.x) / dg.x : xr.x;
-            o.y = dg.y != 0.0 ? xr.y + beta * xr.y + omega * (rr.y - sum.y) / dg.y : xr.y;
+      for (int i = 0; i < NL; ++i)
+        if (i < len[u]) {
+          const double v0 = e[u]->v[0][i], v1 = e[u]->v[1][i], v2 = e[u]->v[2][i];
+          const double va = ca == 0 ? v0 : (ca == 1 ? v1 : v2), vb = cb == 0 ? v0 : (cb == 1 ? v1 : v2);
+          sum.x = sum.x + va * xv[u][i].x;
+          sum.y = sum.y + vb * xv[u][i].y;
+        }
+      dbl2p o;
+      if (EPI == 0) {
+        o = sum;
+      } else {
+        dbl2p rr, dg, xr, yy;
+        if (EPI != 3) { const dbl2u q = *reinterpret_cast<const dbl2u*>(A.rhs + row); rr.x = q.x; rr.y = q.y; }
+        if (EPI == 1 || EPI == 4 || EPI == 5) {
+          const dbl2u q2 = *reinterpret_cast<const dbl2u*>(x + row);
+          xr.x = q2.x; xr.y = q2.y;
+          const int ds = e[u]->dslot;                              // uniform
+          if (ds >= 0) {                                           // the diagonal is an entry of the pattern: no load
+            const double d0 = e[u]->v[0][ds], d1 = e[u]->v[1][ds], d2 = e[u]->v[2][ds];
+            dg.x = ca == 0 ? d0 : (ca == 1 ? d1 : d2);
+            dg.y = cb == 0 ? d0 : (cb == 1 ? d1 : d2);
           } else {
-            o.x = dg.x != 0.0 ? xr.x + beta * (xr.x - yy.x) + omega * (rr.x - sum.x) / dg.x : xr.x;
-            o.y = dg.y != 0.0 ? xr.y + beta * (xr.y - yy.y) + omega * (rr.y - sum.y) / dg.y : xr.y;
+            const dbl2u q1 = *reinterpret_cast<const dbl2u*>(A.diag + row);
+            dg.x = q1.x; dg.y = q1.y;
           }
         }
-        // non-temporal: a plain store allocates the line in L2 and evicts the x windows the neighbouring tiles are
-        // about to gather - measured 0.105 against 0.054 ms on the tile rows (scripts/ubench_gather.hip, v6)
-        dbl2u ou; ou.x = o.x; ou.y = o.y;
-        __builtin_nontemporal_store(ou, reinterpret_cast<dbl2u*>(y + row));
-        if (DOT) { const dbl2u xd = *reinterpret_cast<const dbl2u*>(A.xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+        if (EPI == 3 || EPI == 4) { const dbl2u q = *reinterpret_cast<const dbl2u*>(y + row); yy.x = q.x; yy.y = q.y; }
+        const double omega = A.omega, beta = A.beta;
+        if (EPI == 2) { o.x = rr.x - sum.x; o.y = rr.y - sum.y; }
+        else if (EPI == 3) { o.x = yy.x + omega * sum.x; o.y = yy.y + omega * sum.y; }
+        else if (EPI == 1) {
+          o.x = dg.x != 0.0 ? xr.x + omega * (rr.x - sum.x) / dg.x : xr.x;
+          o.y = dg.y != 0.0 ? xr.y + omega * (rr.y - sum.y) / dg.y : xr.y;
+        } else if (EPI == 5) {
+          o.x = dg.x != 0.0 ? xr.x + beta * xr.x + omega * (rr.x - sum.x) / dg.x : xr.x;
+          o.y = dg.y != 0.0 ? xr.y + beta * xr.y + omega * (rr.y - sum.y) / dg.y : xr.y;
+        } else {
+          o.x = dg.x != 0.0 ? xr.x + beta * (xr.x - yy.x) + omega * (rr.x - sum.x) / dg.x : xr.x;
+          o.y = dg.y != 0.0 ? xr.y + beta * (xr.y - yy.y) + omega * (rr.y - sum.y) / dg.y : xr.y;
+        }
       }
-  }
+      // non-temporal: a plain store allocates the line in L2 and evicts the x windows the neighbouring tiles are
+      // about to gather - measured 0.105 against 0.054 ms on the tile rows (scripts/ubench_gather.hip, v6)
+      dbl2u ou; ou.x = o.x; ou.y = o.y;
+      __builtin_nontemporal_store(ou, reinterpret_cast<dbl2u*>(y + row));
+      if (DOT) { const dbl2u xd = *reinterpret_cast<const dbl2u*>(A.xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+    }
 }
 
 // ---- complex tiles: one row per lane (16 bytes of x per entry), the lane's value list read from the dictionary ------
 template <int TPW>
 __device__ inline void tile_rows_cplx(const TileDesc* __restrict__ desc, const TileEntryC* __restrict__ dict, long long ntiles,
-                                      long long ntb, long long tile_block, const TileArgs& A) {
+                                      long long ntb, long long tile_block, const double* __restrict__ x0, double* __restrict__ y0) {
   const long long tb = tile_xcd_block(tile_block, ntb);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const long long t0 = (tb * TILE_WAVES + wave) * TPW;
   if (!(tb < ntb && t0 < ntiles)) return;
   const int cr = lane % 3;                                         // tiles start at a multiple of three rows of their run
+  const dbl2p* __restrict__ x = reinterpret_cast<const dbl2p*>(x0);
+  dbl2p* __restrict__ y = reinterpret_cast<dbl2p*>(y0);
   for (int u = 0; u < TPW; ++u) {
     if (t0 + u >= ntiles) break;
     const TileDesc d = desc[t0 + u];
@@ -227,149 +230,161 @@ __device__ inline void tile_rows_cplx(const TileDesc* __restrict__ desc, const T
     const int len = e->len;
     const bool on = lane < d.nrows;
     const dbl2p* __restrict__ vp = reinterpret_cast<const dbl2p*>(&e->v[cr][0][0]);
-    for (int j = 0; j < A.k; ++j) {
-      const dbl2p* __restrict__ x = reinterpret_cast<const dbl2p*>(A.x + j * A.ldx);
-      dbl2p* __restrict__ y = reinterpret_cast<dbl2p*>(A.y + j * A.ldy);
-      double sr = 0.0, si = 0.0;
+    double sr = 0.0, si = 0.0;
 #pragma unroll
-      for (int c = 0; c < TL_LONG / 8; ++c)
-        if (c * 8 < len && on) {
-          dbl2p xv[8], vv[8];
+    for (int c = 0; c < TL_LONG / 8; ++c)
+      if (c * 8 < len && on) {
+        dbl2p xv[8], vv[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (c * 8 + i < len) {
-              xv[i] = x[(long long)d.start + e->delta[c * 8 + i] + lane];
-              vv[i] = vp[c * 8 + i];
-            }
+        for (int i = 0; i < 8; ++i)
+          if (c * 8 + i < len) {
+            xv[i] = x[(long long)d.start + e->delta[c * 8 + i] + lane];
+            vv[i] = vp[c * 8 + i];
+          }
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (c * 8 + i < len) {
-              const double pr = vv[i].x * xv[i].x - vv[i].y * xv[i].y;
-              const double pi = vv[i].x * xv[i].y + vv[i].y * xv[i].x;
-              sr = sr + pr;
-              si = si + pi;
-            }
-        }
-      if (on) {
-        dbl2p o; o.x = sr; o.y = si;
-        __builtin_nontemporal_store(o, y + ((long long)d.start + lane));
+        for (int i = 0; i < 8; ++i)
+          if (c * 8 + i < len) {
+            const double pr = vv[i].x * xv[i].x - vv[i].y * xv[i].y;
+            const double pi = vv[i].x * xv[i].y + vv[i].y * xv[i].x;
+            sr = sr + pr;
+            si = si + pi;
+          }
       }
+    if (on) {
+      dbl2p o; o.x = sr; o.y = si;
+      __builtin_nontemporal_store(o, y + ((long long)d.start + lane));
     }
   }
 }
 
 // ---- group rows: ELL slabs of 64 rows, one wavefront per group ----------------------------------------------------
 template <bool CPLX, bool DOT, int EPI, bool HALO>
-__device__ inline void group_rows(long long wg, const TileArgs& A, double& part) {
+__device__ inline void group_rows(long long wg, const GenGroup* __restrict__ ggrp, const double* __restrict__ x,
+                                  double* __restrict__ y, const double* __restrict__ xg, const TileArgs& A, double& part) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const long long gi = wg * TILE_WAVES + wave;
-  if (gi >= A.ngn) return;
+  const long long gb = tile_xcd_block(wg, A.ngbG);                 // groups are in row order: XCD w % 8 walks a contiguous eighth,
+  const long long gi = gb * TILE_WAVES + wave;                     // the part of x its tile workgroups stream through its L2
+  if (gb >= A.ngbG || gi >= A.ngn) return;
   const long long g = A.ng0 + gi;
-  const GenGroup gd = A.ggrp[g];                                   // uniform
+  const GenGroup gd = ggrp[g];                                     // uniform: scalar load
   const int row = A.grow[g * 64 + lane];                           // -1: padding lane of the last group
   const int* __restrict__ cp = A.gcol + gd.off + lane;
   constexpr int W = CPLX ? 2 : 1;
   const double* __restrict__ vp = A.gval + (gd.off + lane) * W;
-  for (int j = 0; j < A.k; ++j) {
-    const double* __restrict__ x = A.x + j * A.ldx;
-    const double* __restrict__ xg = HALO ? A.xg + j * A.ldg : nullptr;
-    double* __restrict__ y = A.y + j * A.ldy;
-    double sr = 0.0, si = 0.0;
-    for (int s0 = 0; s0 < gd.width; s0 += 8) {                     // uniform trip count
-      int cc[8];
-      double vr[8], vi[8], xr[8], xi[8];
+  double sr = 0.0, si = 0.0;
+  for (int s0 = 0; s0 < gd.width; s0 += 8) {                       // uniform trip count
+    int cc[8];
+    double vr[8], vi[8], xr[8], xi[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int s = s0 + i < gd.width ? s0 + i : gd.width - 1;
-        cc[i] = cp[(long long)s * 64];
-        if (CPLX) { const dbl2p t = *reinterpret_cast<const dbl2p*>(vp + (long long)s * 128); vr[i] = t.x; vi[i] = t.y; }
-        else vr[i] = vp[(long long)s * 64];
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int s = s0 + i < gd.width ? s0 + i : gd.width - 1;
+      cc[i] = cp[(long long)s * 64];
+      if (CPLX) { const dbl2p t = *reinterpret_cast<const dbl2p*>(vp + (long long)s * 128); vr[i] = t.x; vi[i] = t.y; }
+      else vr[i] = vp[(long long)s * 64];
+    }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const long long c0 = cc[i] >= 0 ? cc[i] : 0;               // padding slot: any valid address, the product is masked
-        const double* src = (HALO && c0 >= A.nowned) ? xg + (c0 - A.nowned) * W : x + c0 * W;
-        if (CPLX) { const dbl2p t = *reinterpret_cast<const dbl2p*>(src); xr[i] = t.x; xi[i] = t.y; }
-        else xr[i] = *src;
-      }
+    for (int i = 0; i < 8; ++i) {
+      const long long c0 = cc[i] >= 0 ? cc[i] : 0;                 // padding slot: any valid address, the product is masked
+      const double* src = (HALO && c0 >= A.nowned) ? xg + (c0 - A.nowned) * W : x + c0 * W;
+      if (CPLX) { const dbl2p t = *reinterpret_cast<const dbl2p*>(src); xr[i] = t.x; xi[i] = t.y; }
+      else xr[i] = *src;
+    }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bool live = s0 + i < gd.width && cc[i] >= 0;
-        if (CPLX) {
-          const double pr = vr[i] * xr[i] - vi[i] * xi[i];
-          const double pi = vr[i] * xi[i] + vi[i] * xr[i];
-          const double r2 = sr + pr, i2 = si + pi;
-          sr = live ? r2 : sr;
-          si = live ? i2 : si;
-        } else {
-          const double s2 = sr + vr[i] * xr[i];
-          sr = live ? s2 : sr;
-        }
+    for (int i = 0; i < 8; ++i) {
+      const bool live = s0 + i < gd.width && cc[i] >= 0;
+      if (CPLX) {
+        const double pr = vr[i] * xr[i] - vi[i] * xi[i];
+        const double pi = vr[i] * xi[i] + vi[i] * xr[i];
+        const double r2 = sr + pr, i2 = si + pi;
+        sr = live ? r2 : sr;
+        si = live ? i2 : si;
+      } else {
+        const double s2 = sr + vr[i] * xr[i];
+        sr = live ? s2 : sr;
       }
     }
-    if (row >= 0) {
-      if (CPLX) {
-        dbl2p o; o.x = sr; o.y = si;
-        __builtin_nontemporal_store(o, reinterpret_cast<dbl2p*>(y) + row);
-      } else {
-        __builtin_nontemporal_store(tile_epilogue<EPI>(sr, row, x, A.rhs, A.diag, A.omega, A.beta, y), y + row);
-        if (DOT) part += sr * A.xdot[row];
-      }
+  }
+  if (row >= 0) {
+    if (CPLX) {
+      dbl2p o; o.x = sr; o.y = si;
+      __builtin_nontemporal_store(o, reinterpret_cast<dbl2p*>(y) + row);
+    } else {
+      __builtin_nontemporal_store(tile_epilogue<EPI>(sr, row, x, A.rhs, A.diag, A.omega, A.beta, y), y + row);
+      if (DOT) part += sr * A.xdot[row];
     }
   }
 }
 
 // ---- long rows: one thread per row over the CSR arrays, entries in storage order ----------------------------------
 template <bool CPLX, bool DOT, int EPI, bool HALO>
-__device__ inline void long_rows(long long wg, const TileArgs& A, double& part) {
+__device__ inline void long_rows(long long wg, const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ xg,
+                                 const TileArgs& A, double& part) {
   const long long i = wg * TILE_BLOCK + threadIdx.x;
   if (i >= A.nln) return;
   const long long row = A.lrows[A.nl0 + i];
   const long long q0 = A.rowptr[row], q1 = A.rowptr[row + 1];
   constexpr int W = CPLX ? 2 : 1;
-  for (int j = 0; j < A.k; ++j) {
-    const double* __restrict__ x = A.x + j * A.ldx;
-    const double* __restrict__ xg = HALO ? A.xg + j * A.ldg : nullptr;
-    double* __restrict__ y = A.y + j * A.ldy;
-    double sr = 0.0, si = 0.0;
-    for (long long q = q0; q < q1; ++q) {
-      const long long c0 = A.colidx[q];
-      const double* src = (HALO && c0 >= A.nowned) ? xg + (c0 - A.nowned) * W : x + c0 * W;
-      if (CPLX) {
-        const double ar = A.vals[2 * q], ai = A.vals[2 * q + 1], xr = src[0], xi = src[1];
-        const double pr = ar * xr - ai * xi;
-        const double pi = ar * xi + ai * xr;
-        sr = sr + pr;
-        si = si + pi;
-      } else {
-        sr = sr + A.vals[q] * src[0];
-      }
+  double sr = 0.0, si = 0.0;
+  for (long long q = q0; q < q1; ++q) {
+    const long long c0 = A.colidx[q];
+    const double* src = (HALO && c0 >= A.nowned) ? xg + (c0 - A.nowned) * W : x + c0 * W;
+    if (CPLX) {
+      const double ar = A.vals[2 * q], ai = A.vals[2 * q + 1], xr = src[0], xi = src[1];
+      const double pr = ar * xr - ai * xi;
+      const double pi = ar * xi + ai * xr;
+      sr = sr + pr;
+      si = si + pi;
+    } else {
+      sr = sr + A.vals[q] * src[0];
     }
-    if (CPLX) { y[2 * row] = sr; y[2 * row + 1] = si; }
-    else {
-      y[row] = tile_epilogue<EPI>(sr, row, x, A.rhs, A.diag, A.omega, A.beta, y);
-      if (DOT) part += sr * A.xdot[row];
-    }
+  }
+  if (CPLX) { y[2 * row] = sr; y[2 * row + 1] = si; }
+  else {
+    y[row] = tile_epilogue<EPI>(sr, row, x, A.rhs, A.diag, A.omega, A.beta, y);
+    if (DOT) part += sr * A.xdot[row];
   }
 }
 
-// One launch: the first ngb workgroups take the group rows and the long rows (measured: better than spreading them
-// among the tile workgroups), then the short-pattern tiles, then the long-pattern tiles; each range starts at a
-// multiple of 8 so that workgroup w of a range runs on XCD w % 8.
-template <bool CPLX, bool DOT, int EPI, bool HALO>
-__global__ __launch_bounds__(TILE_BLOCK) void k_spmv_tile(const TileArgs A) {
+// One launch.  blockIdx.y is the column of the block of vectors (every workgroup runs straight-line single-column
+// code; a loop over the columns inside the kernel cost more registers than the shared pattern loads saved).
+// blockIdx.x: the workgroups of the group rows and long rows (ngb of them, a multiple of 8) and those of the
+// short-pattern tiles, dealt in octets - one workgroup per XCD - so that workgroup w of either kind runs on XCD w % 8.
+// A.order: 0 group octets first, 1 last, 2 spread evenly among the tile octets.
+// LONGP: the kernel of the long-pattern tiles (9..16 entries) - a launch of its own, made only for matrices that have
+// such tiles: their 48 pattern values per tile would otherwise set the register budget of every product (SGPR spills
+// on the 7-point operators the solver iterates on).
+template <bool CPLX, bool DOT, int EPI, bool HALO, bool LONGP = false>
+__global__ __launch_bounds__(TILE_BLOCK) void k_spmv_tile(
+    const TileDesc* __restrict__ descA, const void* __restrict__ dictA, const GenGroup* __restrict__ ggrp,
+    const double* __restrict__ x0, double* __restrict__ y0, const TileArgs A) {
   double part = 0.0;
   const long long bid = blockIdx.x;
-  const long long ntbA8 = ((A.ntbA + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD;
-  if (bid < A.ngb) {
-    if (bid < A.ngbG) group_rows<CPLX, DOT, EPI, HALO>(bid, A, part);
-    else if (bid < A.ngbG + A.ngbL) long_rows<CPLX, DOT, EPI, HALO>(bid - A.ngbG, A, part);
-  } else if (CPLX) {
-    tile_rows_cplx<TILE_TPW>(A.descA, (const TileEntryC*)A.dictA, A.ntA, A.ntbA, bid - A.ngb, A);
-  } else if (bid < A.ngb + ntbA8) {
-    tile_rows_real<TileEntry8, TL_SHORT, TILE_TPW, DOT, EPI>(A.descA, (const TileEntry8*)A.dictA, A.ntA, A.ntbA, bid - A.ngb, A, part);
+  const double* __restrict__ x = x0 + (long long)blockIdx.y * A.ldx;
+  double* __restrict__ y = y0 + (long long)blockIdx.y * A.ldy;
+  const double* __restrict__ xg = HALO ? A.xg + (long long)blockIdx.y * A.ldg : nullptr;
+  if (LONGP) {
+    tile_rows_real<TileEntry16, TL_LONG, 1, DOT, EPI>(descA, (const TileEntry16*)dictA, A.ntB, A.ntbB, bid, x, y, A, part);
   } else {
-    tile_rows_real<TileEntry16, TL_LONG, 1, DOT, EPI>(A.descB, (const TileEntry16*)A.dictB, A.ntB, A.ntbB, bid - A.ngb - ntbA8, A, part);
+    // octet o of the grid is a group octet or a tile octet
+    const long long G = A.ngb / MXG_NUM_XCD, o = bid / MXG_NUM_XCD, T = gridDim.x / MXG_NUM_XCD;
+    long long gbefore;                                             // group octets in front of octet o
+    bool is_group;
+    if (A.order == 0) { is_group = o < G; gbefore = min(o, G); }
+    else if (A.order == 1) { is_group = o >= T - G; gbefore = max(0LL, o - (T - G)); }
+    else {                                                         // group octet i sits at position floor(i T / G)
+      gbefore = G > 0 ? min(G, (o * G + T - 1) / T) : 0;
+      is_group = gbefore < G && (gbefore * T) / G == o;
+    }
+    const long long lane8 = bid % MXG_NUM_XCD;
+    if (is_group) {
+      const long long wg = gbefore * MXG_NUM_XCD + lane8, ngbG8 = ((A.ngbG + MXG_NUM_XCD - 1) / MXG_NUM_XCD) * MXG_NUM_XCD;
+      if (wg < ngbG8) group_rows<CPLX, DOT, EPI, HALO>(wg, ggrp, x, y, xg, A, part);      // (XCD-mapped inside: octets, not single workgroups)
+      else if (wg - ngbG8 < A.ngbL) long_rows<CPLX, DOT, EPI, HALO>(wg - ngbG8, x, y, xg, A, part);
+    } else {
+      const long long tile_block = (o - gbefore) * MXG_NUM_XCD + lane8;
+      if (CPLX) tile_rows_cplx<TILE_TPW>(descA, (const TileEntryC*)dictA, A.ntA, A.ntbA, tile_block, x, y);
+      else tile_rows_real<TileEntry8, TL_SHORT, TILE_TPW, DOT, EPI>(descA, (const TileEntry8*)dictA, A.ntA, A.ntbA, tile_block, x, y, A, part);
+    }
   }
   if (DOT) tile_block_sum(part, A.partial, bid);
 }
@@ -560,25 +575,36 @@ int upload(void** dst, const std::vector<T>& v, hipStream_t s) {
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 inline long long up8(long long a) { return ceil_div(a, MXG_NUM_XCD) * MXG_NUM_XCD; }
 
-// workgroups of one phase: generic part (groups + long rows, rounded up to 8) + tile ranges (each rounded up to 8)
-struct PhaseGeom { long long ngbG, ngbL, ngb, ntbA, ntbB, grid; };
+// workgroups of one phase: generic part (groups + long rows, rounded up to 8) + short-pattern tiles (rounded up to 8);
+// gridB: the separate launch of the long-pattern tiles
+struct PhaseGeom { long long ngbG, ngbL, ngb, ntbA, ntbB, grid, gridB; };
 PhaseGeom phase_geom(const mxg_csr* a, long long ngroups, long long nlong, bool tiles) {
   PhaseGeom g;
   g.ngbG = ceil_div(ngroups, TILE_WAVES);
   g.ngbL = ceil_div(nlong, TILE_BLOCK);
-  g.ngb = up8(g.ngbG + g.ngbL);
+  g.ngb = up8(g.ngbG) + up8(g.ngbL);
   const int tpw = TILE_TPW;
   g.ntbA = tiles ? ceil_div(a->tile_ntA, (long long)TILE_WAVES * tpw) : 0;
   g.ntbB = tiles ? ceil_div(a->tile_ntB, (long long)TILE_WAVES) : 0;
-  g.grid = g.ngb + up8(g.ntbA) + up8(g.ntbB);
+  g.grid = g.ngb + up8(g.ntbA);
+  g.gridB = up8(g.ntbB);
   return g;
 }
 
 template <bool CPLX, bool DOT, int EPI>
-void launch_phase(mxg_ctx* c, const TileArgs& A, long long grid, bool halo) {
-  if (grid <= 0) return;
-  if (halo) hipLaunchKernelGGL((k_spmv_tile<CPLX, DOT, EPI, true>), dim3((unsigned)grid), dim3(TILE_BLOCK), 0, c->stream, A);
-  else hipLaunchKernelGGL((k_spmv_tile<CPLX, DOT, EPI, false>), dim3((unsigned)grid), dim3(TILE_BLOCK), 0, c->stream, A);
+void launch_phase(mxg_ctx* c, const mxg_csr* a, const double* x, double* y, int k, TileArgs A, const PhaseGeom& g, bool halo) {
+  const GenGroup* gg = (const GenGroup*)a->d_ggrp;
+  if (g.grid > 0) {
+    if (halo) hipLaunchKernelGGL((k_spmv_tile<CPLX, DOT, EPI, true>), dim3((unsigned)g.grid, (unsigned)k), dim3(TILE_BLOCK), 0, c->stream,
+                                 (const TileDesc*)a->d_tiledescA, (const void*)a->d_tiledictA, gg, x, y, A);
+    else hipLaunchKernelGGL((k_spmv_tile<CPLX, DOT, EPI, false>), dim3((unsigned)g.grid, (unsigned)k), dim3(TILE_BLOCK), 0, c->stream,
+                            (const TileDesc*)a->d_tiledescA, (const void*)a->d_tiledictA, gg, x, y, A);
+  }
+  if (!CPLX && g.gridB > 0) {              // long-pattern tiles: their partial sums follow those of the main launch
+    if (A.partial) A.partial += g.grid;
+    hipLaunchKernelGGL((k_spmv_tile<false, DOT, EPI, false, true>), dim3((unsigned)g.gridB, (unsigned)k), dim3(TILE_BLOCK), 0, c->stream,
+                       (const TileDesc*)a->d_tiledescB, (const void*)a->d_tiledictB, gg, x, y, A);
+  }
 }
 
 }  // namespace
@@ -631,9 +657,9 @@ int mxg_tile_build(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doubl
 // partial-sum slots a DOT launch writes (both phases of a row-partitioned matrix)
 int64_t mxg_tile_partials(const mxg_csr* a) {
   const bool halo = a->nghost > 0 || a->nneigh > 0;
-  if (!halo) return phase_geom(a, a->gen_ngrp, a->gen_nlong, true).grid;
-  return phase_geom(a, a->gen_ngrp_interior, a->gen_nlong_interior, true).grid +
-         phase_geom(a, a->gen_ngrp - a->gen_ngrp_interior, a->gen_nlong - a->gen_nlong_interior, false).grid;
+  const PhaseGeom g1 = phase_geom(a, halo ? a->gen_ngrp_interior : a->gen_ngrp, halo ? a->gen_nlong_interior : a->gen_nlong, true);
+  if (!halo) return g1.grid + g1.gridB;
+  return g1.grid + g1.gridB + phase_geom(a, a->gen_ngrp - a->gen_ngrp_interior, a->gen_nlong - a->gen_nlong_interior, false).grid;
 }
 
 // y = epilogue(A x) for k columns (x, y: first column and leading dimension in doubles).  halo: the matrix has ghost
@@ -647,26 +673,25 @@ int mxg_tile_launch(mxg_ctx* c, mxg_csr* a, const double* x, long long ldx, doub
   MXG_CHECK(!(a->is_complex && (epi != 0 || dot)), "mxg_tile_launch: complex products have no fused epilogue");
   MXG_CHECK(k == 1 || (epi == 0 && !dot), "mxg_tile_launch: fused epilogues take one column");
   TileArgs A{};
-  A.descA = (const TileDesc*)a->d_tiledescA; A.dictA = a->d_tiledictA; A.ntA = a->tile_ntA;
-  A.descB = (const TileDesc*)a->d_tiledescB; A.dictB = a->d_tiledictB; A.ntB = a->tile_ntB;
-  A.ggrp = (const GenGroup*)a->d_ggrp; A.grow = a->d_grow; A.gcol = a->d_gcol; A.gval = a->d_gval;
+  A.ntA = a->tile_ntA; A.ntB = a->tile_ntB;
+  A.grow = a->d_grow; A.gcol = a->d_gcol; A.gval = a->d_gval;
   A.lrows = a->d_lrows;
   A.rowptr = (const long long*)a->d_rowptr; A.colidx = a->d_colidx; A.vals = a->d_vals;
-  A.x = x; A.ldx = ldx; A.y = y; A.ldy = ldy; A.k = k;
+  A.ldx = ldx; A.ldy = ldy; A.order = TILE_ORDER;
   A.xdot = xdot; A.partial = partial; A.rhs = rhs; A.diag = diag; A.omega = omega; A.beta = beta;
   A.xg = xg; A.ldg = ldg; A.nowned = a->ncols_owned;
   auto run = [&](const PhaseGeom& g, bool h) {
     A.ngbG = g.ngbG; A.ngbL = g.ngbL; A.ngb = g.ngb; A.ntbA = g.ntbA; A.ntbB = g.ntbB;
     if (g.ntbA == 0) A.ntA = 0;
     if (g.ntbB == 0) A.ntB = 0;
-    if (a->is_complex) launch_phase<true, false, 0>(c, A, g.grid, h);
-    else if (dot) launch_phase<false, true, 0>(c, A, g.grid, h);
-    else if (epi == 1) launch_phase<false, false, 1>(c, A, g.grid, h);
-    else if (epi == 2) launch_phase<false, false, 2>(c, A, g.grid, h);
-    else if (epi == 3) launch_phase<false, false, 3>(c, A, g.grid, h);
-    else if (epi == 4) launch_phase<false, false, 4>(c, A, g.grid, h);
-    else if (epi == 5) launch_phase<false, false, 5>(c, A, g.grid, h);
-    else launch_phase<false, false, 0>(c, A, g.grid, h);
+    if (a->is_complex) launch_phase<true, false, 0>(c, a, x, y, k, A, g, h);
+    else if (dot) launch_phase<false, true, 0>(c, a, x, y, k, A, g, h);
+    else if (epi == 1) launch_phase<false, false, 1>(c, a, x, y, k, A, g, h);
+    else if (epi == 2) launch_phase<false, false, 2>(c, a, x, y, k, A, g, h);
+    else if (epi == 3) launch_phase<false, false, 3>(c, a, x, y, k, A, g, h);
+    else if (epi == 4) launch_phase<false, false, 4>(c, a, x, y, k, A, g, h);
+    else if (epi == 5) launch_phase<false, false, 5>(c, a, x, y, k, A, g, h);
+    else launch_phase<false, false, 0>(c, a, x, y, k, A, g, h);
   };
   if (!halo) {
     A.ng0 = 0; A.ngn = a->gen_ngrp; A.nl0 = 0; A.nln = a->gen_nlong;
@@ -679,7 +704,7 @@ int mxg_tile_launch(mxg_ctx* c, mxg_csr* a, const double* x, long long ldx, doub
     A.ntA = 0; A.ntB = 0;
     A.ng0 = a->gen_ngrp_interior; A.ngn = a->gen_ngrp - a->gen_ngrp_interior;
     A.nl0 = a->gen_nlong_interior; A.nln = a->gen_nlong - a->gen_nlong_interior;
-    if (partial) A.partial = partial + g1.grid;
+    if (partial) A.partial = partial + g1.grid + g1.gridB;
     run(phase_geom(a, A.ngn, A.nln, false), true);
   }
   if (hipGetLastError() != hipSuccess) { mxg_set_error("mxg_tile_launch: launch failed"); return 1; }

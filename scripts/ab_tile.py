@@ -20,7 +20,7 @@ def timed(A, X, Y, reps=reps):
     return ctx.timer_stop() / reps
 
 
-for name in ("vecLapl", "scaLapl"):
+for name in ("vecLapl",):
     A = sim.to_device(ctx, name, shift=shift if name == "vecLapl" else 0.0)
     X = mx.MultiVec(ctx, A.ncols, 1); Y = mx.MultiVec(ctx, A.nrows, 1); X.random(1)
     alg = A.apply_bytes(1)
@@ -44,7 +44,7 @@ for name in ("vecLapl", "scaLapl"):
             for k in (2, 4, 8):
                 Xk = mx.MultiVec(ctx, B.ncols, k); Yk = mx.MultiVec(ctx, B.nrows, k); Xk.random(3)
                 ms = timed(B, Xk, Yk, 20)
-                A.apply(Xk, Yk); want = Yk.to_numpy(); B.apply(Xk, Yk)
+                A.apply(Xk, Yk); want = Yk.to_numpy(); Yk.fill(float('nan')); B.apply(Xk, Yk)
                 r["tile_k%d" % k] = {"ms": ms, "eff_frac_csr_formula": B.apply_bytes(k) / ms / 8e9,
                                      "same": bool(np.array_equal(want, Yk.to_numpy())), "csr_ms": timed(A, Xk, Yk, 20)}
                 Xk.close(); Yk.close()
