@@ -56,11 +56,12 @@ struct TileEntry16 {                                                 // long pat
   int pad1[8];
 };
 static_assert(sizeof(TileEntry8) == 256 && sizeof(TileEntry16) == 512, "tile dictionary entry layout");
-struct TileEntryC {                                                  // complex: 1024 bytes, read with vector loads
-  int len, dslot, pad0[6];
-  int delta[16];                                                     // in complex elements
+struct TileEntryC {                                                  // complex: 1024 bytes, read with vector loads by the lanes
+  int maxlen, pad0[3];
+  int len[4];                                                        // per row offset 0, 1, 2 mod 3: the three components of a
+  int delta[3][16];                                                  // cell may have different shapes (in complex elements)
   double v[3][16][2];
-  int pad1[40];
+  int pad1[8];
 };
 static_assert(sizeof(TileEntryC) == 1024, "complex tile dictionary entry layout");
 struct GenGroup { long long off; int width, pad; };                  // off: first slot of the group in gcol / gval (64 per entry slot)
@@ -212,7 +213,10 @@ __device__ inline void tile_rows_real(const TileDesc* __restrict__ desc, const E
     }
 }
 
-// ---- complex tiles: one row per lane (16 bytes of x per entry), the lane's value list read from the dictionary ------
+// ---- complex tiles: one row per lane (16 bytes of x per entry); the lane reads the shape and the values of its row
+// offset mod 3 from the dictionary with vector loads (three distinct addresses per instruction), so the three
+// components of a cell may have different shapes: the lossy-dielectric operator of config 5 has 15-entry rows whose
+// cross-component entries are complex rounding residue (kept by purgeZeros as in the reference), shaped per component
 template <int TPW>
 __device__ inline void tile_rows_cplx(const TileDesc* __restrict__ desc, const TileEntryC* __restrict__ dict, long long ntiles,
                                       long long ntb, long long tile_block, const double* __restrict__ x0, double* __restrict__ y0) {
@@ -227,27 +231,31 @@ __device__ inline void tile_rows_cplx(const TileDesc* __restrict__ desc, const T
     if (t0 + u >= ntiles) break;
     const TileDesc d = desc[t0 + u];
     const TileEntryC* __restrict__ e = dict + d.pid;
-    const int len = e->len;
+    const int maxlen = e->maxlen;                                  // uniform
     const bool on = lane < d.nrows;
+    const int mylen = on ? e->len[cr] : 0;
+    const int* __restrict__ dp = e->delta[cr];
     const dbl2p* __restrict__ vp = reinterpret_cast<const dbl2p*>(&e->v[cr][0][0]);
     double sr = 0.0, si = 0.0;
 #pragma unroll
     for (int c = 0; c < TL_LONG / 8; ++c)
-      if (c * 8 < len && on) {
+      if (c * 8 < maxlen) {
         dbl2p xv[8], vv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (c * 8 + i < len) {
-            xv[i] = x[(long long)d.start + e->delta[c * 8 + i] + lane];
+          if (c * 8 + i < maxlen) {
+            const bool live = c * 8 + i < mylen;
+            xv[i] = x[live ? (long long)d.start + dp[c * 8 + i] + lane : 0];   // dead slot: any valid address, the product is masked
             vv[i] = vp[c * 8 + i];
           }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (c * 8 + i < len) {
+          if (c * 8 + i < maxlen) {
             const double pr = vv[i].x * xv[i].x - vv[i].y * xv[i].y;
             const double pi = vv[i].x * xv[i].y + vv[i].y * xv[i].x;
-            sr = sr + pr;
-            si = si + pi;
+            const double r2 = sr + pr, i2 = si + pi;
+            sr = c * 8 + i < mylen ? r2 : sr;
+            si = c * 8 + i < mylen ? i2 : si;
           }
       }
     if (on) {
@@ -416,10 +424,11 @@ unsigned plan_threads(int64_t n) {
   return nthreads;
 }
 
-// Runs of rows with one length (<= 16) and one list of column offsets, none of them a ghost column, in which each row
-// repeats the values of the row three before it, cut into tiles (real: <= 126 rows, even; complex: <= 63 rows; every
-// tile starts a multiple of three rows into its run).  All other rows become group rows or long rows, the ones that
-// read no ghost column first.
+// Runs of rows of <= 16 entries, none of them in a ghost column, in which each row repeats the column offsets and the
+// values of the row three before it - and, for real scalars, the column offsets of the row before it (two rows of a
+// lane share their gathers; a complex lane holds one row, so the three components may be shaped differently) - cut
+// into tiles (real: <= 126 rows, even; complex: <= 63 rows; every tile starts a multiple of three rows into its run).
+// All other rows become group rows or long rows, the ones that read no ghost column first.
 void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n, int64_t nowned, bool cplx, TilePlan& P) {
   P = TilePlan();
   P.cplx = cplx;
@@ -446,9 +455,9 @@ void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n
       pool.emplace_back([&, i] {
         for (int64_t r = n * i / nthreads; r < n * (i + 1) / nthreads; ++r) {
           unsigned char f = 0;
-          if (r >= 1 && rp[r + 1] - rp[r] <= maxlen && same_shape(r, r - 1)) {
-            f = 1;
-            if (r >= 3 && same_shape(r, r - 3) && same_vals(r, r - 3)) f = 3;
+          if (rp[r + 1] - rp[r] <= maxlen) {
+            if (r >= 1 && same_shape(r, r - 1)) f |= 1;
+            if (r >= 3 && same_shape(r, r - 3) && same_vals(r, r - 3)) f |= 2;
           }
           for (int64_t q = rp[r]; q < rp[r + 1]; ++q)
             if (ci[q] >= nowned) { f |= 4; break; }
@@ -467,21 +476,28 @@ void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n
     int64_t e = r + 1;
     const int len = (int)(rp[r + 1] - rp[r]);
     if (len <= maxlen && !(step[(size_t)r] & 4)) {
-      while (e < n && (step[(size_t)e] & 1) && !(step[(size_t)e] & 4) && (e - r < 3 || (step[(size_t)e] & 2))) ++e;
+      if (cplx)
+        while (e < n && !(step[(size_t)e] & 4) && (e - r < 3 ? rp[e + 1] - rp[e] <= maxlen : (step[(size_t)e] & 2) != 0)) ++e;
+      else
+        while (e < n && (step[(size_t)e] & 1) && !(step[(size_t)e] & 4) && (e - r < 3 || (step[(size_t)e] & 2))) ++e;
     }
     int64_t len_run = e - r;
     if (!cplx && (len_run & 1)) --len_run;                          // real tiles hold an even number of rows
     if (len_run >= TILE_MIN_RUN) {
       const bool is_long = !cplx && len > TL_SHORT;
-      sg.assign(4 + (size_t)len * 4 + (size_t)len * 24 * w, '\0');
-      std::memcpy(&sg[0], &len, 4);
+      // signature: the shapes and values of the rows r, r+1, r+2 (len_run >= 24: they exist in the run)
+      sg.clear();
       int dslot = -1, ndiag = 0;
-      for (int i = 0; i < len; ++i) {
-        const int32_t dl = (int32_t)((int64_t)ci[rp[r] + i] - r);
-        if (dl == 0) { dslot = i; ++ndiag; }
-        std::memcpy(&sg[4 + (size_t)i * 4], &dl, 4);
-        for (int k = 0; k < 3; ++k)                                 // len_run >= 24: rows r, r+1, r+2 exist in the run
-          std::memcpy(&sg[4 + (size_t)len * 4 + ((size_t)i * 3 + k) * 8 * w], va + (rp[r + k] + i) * w, 8 * (size_t)w);
+      for (int k = 0; k < 3; ++k) {
+        const int64_t q0 = rp[r + k];
+        const int lk = (int)(rp[r + k + 1] - q0);
+        sg.append(reinterpret_cast<const char*>(&lk), 4);
+        for (int i = 0; i < lk; ++i) {
+          const int32_t dl = (int32_t)((int64_t)ci[q0 + i] - (r + k));
+          if (k == 0 && dl == 0) { dslot = i; ++ndiag; }
+          sg.append(reinterpret_cast<const char*>(&dl), 4);
+        }
+        sg.append(reinterpret_cast<const char*>(va + q0 * w), sizeof(double) * (size_t)lk * w);
       }
       if (ndiag != 1) dslot = -1;                                   // d_diag sums repeated diagonal entries: read it then
       auto& ids = is_long ? idsB : idsA;
@@ -492,10 +508,14 @@ void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n
       } else {
         if (cplx) {
           TileEntryC te{};
-          te.len = len; te.dslot = dslot;
-          for (int i = 0; i < len; ++i) {
-            te.delta[i] = (int32_t)((int64_t)ci[rp[r] + i] - r);
-            for (int k = 0; k < 3; ++k) { te.v[k][i][0] = va[(rp[r + k] + i) * 2]; te.v[k][i][1] = va[(rp[r + k] + i) * 2 + 1]; }
+          for (int k = 0; k < 3; ++k) {
+            const int64_t q0 = rp[r + k];
+            te.len[k] = (int)(rp[r + k + 1] - q0);
+            te.maxlen = std::max(te.maxlen, te.len[k]);
+            for (int i = 0; i < te.len[k]; ++i) {
+              te.delta[k][i] = (int32_t)((int64_t)ci[q0 + i] - (r + k));
+              te.v[k][i][0] = va[(q0 + i) * 2]; te.v[k][i][1] = va[(q0 + i) * 2 + 1];
+            }
           }
           id = (int)P.dictC.size(); P.dictC.push_back(te);
         } else if (is_long) {
@@ -751,8 +771,9 @@ extern "C" int mxg_debug_tile_plan_apply(int64_t nrows, int64_t ncols_owned, con
       for (int t = 0; t < d.nrows; ++t) {
         const int64_t row = (int64_t)d.start + t;
         double sr = 0.0, si = 0.0;
-        for (int i = 0; i < e.len; ++i) {
-          const double ar = e.v[t % 3][i][0], ai = e.v[t % 3][i][1], xr = x[(row + e.delta[i]) * 2], xi = x[(row + e.delta[i]) * 2 + 1];
+        if (e.len[t % 3] > e.maxlen || e.maxlen > TL_LONG) dup += 1000;
+        for (int i = 0; i < e.len[t % 3]; ++i) {
+          const double ar = e.v[t % 3][i][0], ai = e.v[t % 3][i][1], xr = x[(row + e.delta[t % 3][i]) * 2], xi = x[(row + e.delta[t % 3][i]) * 2 + 1];
           const double pr = ar * xr - ai * xi, pi = ar * xi + ai * xr;
           sr = sr + pr; si = si + pi;
         }

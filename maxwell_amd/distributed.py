@@ -206,6 +206,12 @@ class DistMatrix:
         _chk(self.ctx.lib.mxg_csr_compress(self.h, C.byref(nb), C.byref(nf), C.byref(sb)), self.ctx.lib)
         return nb.value, nf.value, sb.value
 
+    def product_form(self):
+        """(form, tiles, tile patterns, irregular rows, coverage): form 0 plain CSR, 1 compressed stream, 3 tile patterns."""
+        t, p, g, cov = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
+        form = self.ctx.lib.mxg_csr_product_form(self.h, C.byref(t), C.byref(p), C.byref(g), C.byref(cov))
+        return form, t.value, p.value, g.value, cov.value
+
 
 def bench_setup(ctx, n_local, shift):
     """Weak-scaling workload of bench.py: the pillbox cavity of example/pillbox.py on a grid refined so

@@ -5,6 +5,8 @@ inner products, rank-local multigrid blocks - against the single-rank solve and 
 RCCL refuses two ranks on one device, so on the one-GPU test box the ranks are threads of an in-process world
 (mxg_local_world, include/mxg.h): the same collectives, the same call sequence, staged through the host.  The
 RCCL world runs the identical code above mxg_comm_* (maxwell_amd/csrc/device/mxg_comm.hip)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -26,10 +28,13 @@ def _run_ranks(nranks, fn):
         world.close()
 
 
-@pytest.mark.parametrize("nranks", [2, 4])
-def test_row_partitioned_product_matches_global(built, nranks):
-    """y = (vecLapl - shift dmA) x and the rectangular divB / gradPsi with real neighbour exchanges: every rank's
-    owned rows equal the rows of the oracle's global product bit for bit; norms are all-reduced."""
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_row_partitioned_product_matches_global(built, nranks, monkeypatch):
+    """y = (vecLapl - shift dmA) x and the rectangular divB / gradPsi with real neighbour exchanges on 2x1x1, 2x2x1 and
+    2x2x2 boxes (src/MxGrid.cpp:171-193; 2x2x2 is the decomposition of BASELINE config 4): every rank's owned rows
+    equal the rows of the oracle's global product bit for bit - CSR kernel, compressed stream and the tile form with
+    its ghost-reading group rows, one column and a block of three; norms are all-reduced."""
+    monkeypatch.setenv("MXG_TILE_MIN_COVERAGE", "0")          # small boxes: take the tile form whatever its coverage
     n = [12, 10, 14]
     shift = 1.7
     from oracle import geometry as geo
@@ -53,16 +58,31 @@ def test_row_partitioned_product_matches_global(built, nranks):
             y = mx.MultiVec(ctx, M.nrows, 1)
             M.apply(x, y)
             out[name] = (M.row_gids.copy(), y.to_numpy()[:, 0].copy(), y.norm2()[0])
-            # the same product from the compressed stream (3 B/entry): interior blocks first, boundary blocks read
-            # the ghost buffer after the exchange - bit-identical to the CSR kernel
-            nb, nfall, _ = M.compress()
-            y2 = mx.MultiVec(ctx, M.nrows, 1)
-            M.apply(x, y2)
-            assert nb > 0 and np.array_equal(y2.to_numpy(), y.to_numpy()), name
+            x3 = mx.MultiVec(ctx, M.ncols_owned, 3); x3.random(11 + ctx.rank)
+            y3 = mx.MultiVec(ctx, M.nrows, 3)
+            M.apply(x3, y3)
+            want3 = y3.to_numpy().copy()
+            # the same products from the re-encoded forms, bit-identical to the CSR kernel.  Compressed stream (3 B per
+            # entry): interior blocks first, boundary blocks read the ghost buffer after the exchange.  Tile form: tiles
+            # and ghost-free group rows run while the halo is in flight, ghost-reading group rows behind the halo event.
+            for form in (1, 3):
+                os.environ["MXG_PAT"] = "0" if form == 1 else "1"      # (every rank thread writes the same value)
+                nb, nfall, _ = M.compress()
+                assert nb > 0 and M.product_form()[0] == form, (name, form, M.product_form())
+                y2 = mx.MultiVec(ctx, M.nrows, 1); y2.fill(float("nan"))
+                M.apply(x, y2)
+                assert np.array_equal(y2.to_numpy(), y.to_numpy()), (name, form)
+                y3.fill(float("nan"))
+                M.apply(x3, y3)
+                assert np.array_equal(y3.to_numpy(), want3), (name, form, "block of 3")
+                ctx.barrier()                                            # nobody re-encodes while another rank still reads the switch
         ops.close()
         return out
 
-    res = _run_ranks(nranks, rank)
+    try:
+        res = _run_ranks(nranks, rank)
+    finally:
+        os.environ.pop("MXG_PAT", None)
     for name, rowfield in (("shifted", "bfield"), ("divB", "psifield"), ("gradPsi", "bfield")):
         seen = 0
         for r in range(nranks):
@@ -75,10 +95,13 @@ def test_row_partitioned_product_matches_global(built, nranks):
         assert seen == len(want[name])
 
 
-@pytest.mark.parametrize("nranks,lin_type,prec", [(2, "cg", "amg"), (4, "cg", "amg"), (2, "gmres", "jacobi")])
-def test_decomposed_eigensolve_matches_single_rank(ctx, oracle_pillbox16, nranks, lin_type, prec):
-    """MxSolver on 2 / 4 boxes: same eigenvalues as on one rank and as the oracle's shift-invert of the global
-    pencil, to north_star's 1e-8; residuals and divergences (all-reduced norms) as the reference prints them."""
+@pytest.mark.parametrize("nranks,lin_type,prec", [(2, "cg", "amg"), (4, "cg", "amg"), (8, "cg", "amg"), (2, "gmres", "jacobi")])
+def test_decomposed_eigensolve_matches_single_rank(ctx, oracle_pillbox16, nranks, lin_type, prec, monkeypatch):
+    """MxSolver on 2 / 4 / 8 boxes (8 = 2x2x2, the decomposition of BASELINE config 4): same eigenvalues as on one rank
+    and as the oracle's shift-invert of the global pencil, to north_star's 1e-8; residuals and divergences (all-reduced
+    norms) as the reference prints them.  The operators and multigrid levels run the tile form with ghost-reading group
+    rows (forced: the boxes of a 16^3 grid are too small for its coverage threshold)."""
+    monkeypatch.setenv("MXG_TILE_MIN_COVERAGE", "0")
     from tests.test_eigen_gpu import _oracle_physical_modes, REL_TOL
     _, o = oracle_pillbox16
     shift = yee.default_shift([1, 1, 1])

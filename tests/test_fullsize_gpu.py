@@ -1,7 +1,11 @@
-"""BASELINE config 2 at its full size (pillbox 256^3: 20.6 M rows, 146 M non-zeros) on the GPU:
-bit parity with the oracle's serial row loop on the whole matrix, the size-independent properties of the
-operators (linearity, symmetry, div curl = 0), CSR vs compressed-stream kernel, and the eigenpairs against
-the analytic cavity modes at the O(h^2) discretisation error."""
+"""The BASELINE configurations at their full sizes on the GPU.  Config 2 (pillbox 256^3: 20.6 M rows, 146 M non-zeros):
+bit parity with the oracle's serial row loop on the whole matrix, the size-independent properties of the operators
+(linearity, symmetry, div curl = 0), CSR kernel vs the re-encoded forms, the eigenpairs against the analytic cavity
+modes at the O(h^2) discretisation error.  Config 3 (cylinder 256^3).  Config 4's grid (pillbox 512^3, 1.6e8 rows) on
+one GPU.  Config 5 (dielectric sphere in a PEC sphere, 256^3, block of 8 right-hand sides), real and with a loss
+tangent (complex scalars)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -40,12 +44,18 @@ def test_full_size_spmv_bit_exact_and_properties(ctx, sim256):
     A.apply(Z, AZ)
     az = AZ.to_numpy()[:, 0]
     assert np.abs(az - (2.0 * ax - 3.0 * ay)).max() <= 1e-12 * np.abs(az).max()
-    # the compressed-stream encoding of the same matrix gives the same bits
-    nb, nf, nbytes = A.compress()
-    assert nf < nb and nbytes < A.nnz * 5
-    AC = mx.MultiVec(ctx, A.nrows, 1)
-    A.apply(X, AC)
-    assert np.array_equal(AC.to_numpy()[:, 0], ax)
+    # the re-encoded forms of the same matrix give the same bits: tile form (what the solver runs), compressed stream
+    for pat, form in ((None, 3), ("0", 1)):
+        if pat is not None:
+            os.environ["MXG_PAT"] = pat
+        try:
+            nb, nf, nbytes = A.compress()
+        finally:
+            os.environ.pop("MXG_PAT", None)
+        assert A.product_form()[0] == form and nf < nb and nbytes < A.nnz * 5
+        AC = mx.MultiVec(ctx, A.nrows, 1); AC.fill(float("nan"))
+        A.apply(X, AC)
+        assert np.array_equal(AC.to_numpy()[:, 0], ax), form
     # div curl = 0: the discrete structure the projection of MxMagWaveOp::Apply relies on
     curlE = sim.to_device(ctx, "curlE"); divB = sim.to_device(ctx, "divB")
     e = mx.MultiVec(ctx, curlE.ncols, 1); e.random(7)
@@ -87,23 +97,90 @@ def test_config3_cylinder_full_size_bit_exact(ctx, built):
     sim.close()
 
 
-def test_config5_dielectric_block_of_8_bit_exact(ctx, built):
-    """BASELINE config 5 operator (eps = 10 sphere in a PEC sphere, octant box, FIT inverse permittivity) at
-    128^3 with a block of 8 right-hand sides: SpMM bit for bit against the serial row loop."""
-    sim = mx.Sim(128, origin=(0.0,) * 3, size=(0.5,) * 3, lower=("pmc", "pmc", "pec"), upper=("pec",) * 3,
-                 pec_shape="sphere(0.49;0,0,0)", dielectrics=[(10.0, "sphere(0.37;0,0,0)")])
-    A = sim.to_device(ctx, "vecLapl", shift=0.5)
-    host = sim.op("vecLapl", shift=0.5)
+CONFIG5 = dict(origin=(0.0,) * 3, size=(0.5,) * 3, lower=("pmc", "pmc", "pec"), upper=("pec",) * 3, pec_shape="sphere(0.49;0,0,0)")
+
+
+def _config5_operator(ctx, loss_tangent):
+    """(device matrix, scipy copy) of vecLapl - 0.5 mRhs of the config-5 problem at N^3 cells."""
+    if loss_tangent == 0.0:
+        sim = mx.Sim(N, dielectrics=[(10.0, "sphere(0.37;0,0,0)")], **CONFIG5)
+        A = sim.to_device(ctx, "vecLapl", shift=0.5)
+        host = sim.op("vecLapl", shift=0.5)
+        sim.close()
+        return A, host
+    # complex FIT inverse permittivity: the deck route (MxProblem -> complex assembler), src/MxProblem.cpp:491-492
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    deck = open(os.path.join(root, "tests", "golden", "dsphmsph.mx")).read().replace(
+        "resolution = [12, 12, 12]", "resolution = [%d, %d, %d]" % (N, N, N)).replace(
+        "eps off diag = [0.0, 0.0, 0.0]", "eps off diag = [0.0, 0.0, 0.0]\n    loss tangent = %r" % loss_tangent)
+    prob = mx.Problem(text=deck)
+    assert prob.is_complex
+    host = (prob.op("vecLapl") - 0.5 * prob.op("mRhs")).tocsr()
+    host.sort_indices()
+    del prob
+    return mx.CsrMatrix.from_scipy(ctx, host), host
+
+
+@pytest.mark.parametrize("loss_tangent", [0.0, 1e-3])
+def test_config5_dielectric_256_block_of_8(ctx, built, loss_tangent):
+    """BASELINE config 5 at its stated size: eps = 10 sphere in a PEC sphere, octant box, FIT inverse permittivity,
+    256^3 cells, a block of 8 right-hand sides; real scalars and - with a loss tangent - complex ones
+    (src/MxProblem.cpp:491-492: complex InvEps; src/MxSolver.cpp:28-31: the block).  CSR kernel and tile form (all 8
+    columns in one launch) agree bit for bit on every row of every column; one column is checked against the oracle's
+    serial row loop over the whole matrix; linearity across the block."""
+    cplx = loss_tangent != 0.0
+    A, host = _config5_operator(ctx, loss_tangent)
+    assert A.is_complex == cplx and A.nrows > 2.4e7
     assert abs(host - host.T).max() > 1e-3                        # the FIT inverse permittivity is not symmetric
-    x = np.random.default_rng(5).uniform(-1, 1, (A.ncols, 8))
-    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, A.nrows, 8)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (A.ncols, 8))
+    if cplx:
+        x = x + 1j * rng.uniform(-1, 1, (A.ncols, 8))
+    x[:, 7] = 2.0 * x[:, 0] - 3.0 * x[:, 1]                        # linearity rides along
+    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, A.nrows, 8, cplx)
     A.apply(X, Y)
     got = Y.to_numpy()
-    for j in range(8):
-        assert np.array_equal(got[:, j], cref.spmv(host, x[:, j])), j
+    assert np.array_equal(got[:, 3], cref.spmv(host, x[:, 3]))    # every row of one column against the oracle
+    del host
+    scale = np.abs(got).max()
+    assert np.abs(got[:, 7] - (2.0 * got[:, 0] - 3.0 * got[:, 1])).max() <= 1e-12 * scale
     A.compress()
+    form, tiles, pats, irregular, cov = A.product_form()
+    assert form == 3 and cov > 0.8, (form, cov)
+    Y2 = mx.MultiVec(ctx, A.nrows, 8, cplx); Y2.fill(float("nan"))
+    A.apply(X, Y2)
+    assert np.array_equal(Y2.to_numpy(), got)                     # tile form == CSR kernel, 8 columns, every row
+    for obj in (X, Y, Y2, A):
+        obj.close()
+
+
+def test_config4_grid_512_on_one_gpu(ctx, built):
+    """The grid of BASELINE config 4 (pillbox 512^3: 1.63e8 rows, 1.15e9 non-zeros) on ONE GPU: the tile form against
+    the CSR kernel on every row, symmetry of the pencil and linearity.  (The 2x2x2 decomposition of the same problem
+    runs in tests/test_dist_eigen_gpu.py at test size; RCCL with N > 1 ranks needs N devices.)"""
+    try:
+        avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) // 2 ** 20
+    except Exception:
+        avail = 0
+    if avail < 200:
+        pytest.skip("host memory: the 512^3 assembly peaks at 171 GiB, %d GiB available" % avail)
+    sim = mx.Sim.pillbox(512)
+    A = sim.to_device(ctx, "vecLapl", shift=SHIFT)
+    assert A.nrows > 1.6e8 and A.nnz > 1.1e9
+    X = mx.MultiVec(ctx, A.ncols, 2); X.random(512)
+    Y = mx.MultiVec(ctx, A.nrows, 2)
     A.apply(X, Y)
-    got = Y.to_numpy()
-    for j in (0, 7):
-        assert np.array_equal(got[:, j], cref.spmv(host, x[:, j])), j
+    x, ax = X.to_numpy(), Y.to_numpy()
+    assert abs(x[:, 1] @ ax[:, 0] - x[:, 0] @ ax[:, 1]) <= 1e-11 * np.linalg.norm(x[:, 1]) * np.linalg.norm(ax[:, 0])
+    Z = mx.MultiVec.from_numpy(ctx, 2.0 * x[:, :1] - 3.0 * x[:, 1:]); AZ = mx.MultiVec(ctx, A.nrows, 1)
+    A.apply(Z, AZ)
+    az = AZ.to_numpy()[:, 0]
+    assert np.abs(az - (2.0 * ax[:, 0] - 3.0 * ax[:, 1])).max() <= 1e-12 * np.abs(az).max()
+    del x, az
+    A.compress()
+    form, tiles, pats, irregular, cov = A.product_form()
+    assert form == 3 and cov > 0.95
+    Y2 = mx.MultiVec(ctx, A.nrows, 2); Y2.fill(float("nan"))
+    A.apply(X, Y2)
+    assert np.array_equal(Y2.to_numpy(), ax)                      # 1.6e8 rows x 2 columns, bit for bit
     sim.close()

@@ -466,6 +466,16 @@ def test_tile_form_complex_operator(ctx, rng, monkeypatch):
     assert np.array_equal(got[:, [1, 3, 0]], cref.spmv(m, x[:, [4, 0, 2]])) and np.all(got[:, [2, 4]] == 0)
     A.apply(X, X)                                        # aliasing: works from a copy of x
     assert np.array_equal(X.to_numpy(), cref.spmv(m, x))
+    # 13-point curl-curl: per-component shapes, read per lane from the dictionary
+    m = o["curlCurl"].tocsr().astype(np.complex128)
+    A = mx.CsrMatrix.from_scipy(ctx, m)
+    A.compress()
+    form, tiles, pats, irregular, cov = A.product_form()
+    assert form == 3 and cov > 0.5
+    x = rng.uniform(-1, 1, (m.shape[1], 2)) + 1j * rng.uniform(-1, 1, (m.shape[1], 2))
+    X = mx.MultiVec.from_numpy(ctx, x); Y = mx.MultiVec(ctx, m.shape[0], 2, True); Y.fill(float("nan"))
+    A.apply(X, Y)
+    assert np.array_equal(Y.to_numpy(), cref.spmv(m, x))
 
 
 def test_tile_form_long_patterns_and_wide_groups(ctx, rng, monkeypatch):

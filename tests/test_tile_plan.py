@@ -69,6 +69,22 @@ def test_complex_operator(built, rng):
     assert st["tilesA"] > 0
 
 
+def test_complex_tiles_with_per_component_shapes(built, rng):
+    """The 13-point curl-curl: the three components of a cell have different column offsets.  A complex lane holds
+    one row and reads its own component's shape from the dictionary, so these rows tile (a real lane pairs two rows on
+    shared gathers and needs one shape: the real curl-curl has no tiles)."""
+    s = yee.YeeSim(12, strict=False, phase_shifts=(0.3, 0.0, 0.7))
+    m = s.wave_ops()["curlCurl"].tocsr()
+    x = rng.uniform(-1, 1, m.shape[1]) + 1j * rng.uniform(-1, 1, m.shape[1])
+    rc, y, st = _plan_apply(built, m.astype(np.complex128), x)
+    assert rc == 0, st
+    assert np.array_equal(y, cref.spmv(m.astype(np.complex128), x))
+    assert st["covered"] > 0.5 * m.shape[0], st
+    rc, y, st = _plan_apply(built, m.real.tocsr(), x.real)
+    assert rc == 0 and st["covered"] < 0.2 * m.shape[0], st
+    assert np.array_equal(y, cref.spmv(m.real.tocsr(), x.real))
+
+
 def test_ghost_columns_are_group_rows(built, oracle_pillbox12, rng):
     """Part of the columns re-routed to ghost slots: no tile and no ghost-free group may read them."""
     _, o = oracle_pillbox12
