@@ -1129,14 +1129,8 @@ Csr<S> YeeAssembler<S>::invMuVolAve() const {
     }
     if (muLossy_) acc = acc + Cx((1.0 - sums) * (3.0 / 3.0), 0.0);
     else { out = out + (1.0 - sums) * (3.0 / 3.0); acc = Cx(out, 0.0); }
-    if (hasPml()) {                                       // the layer's 'volume', :765-777: det of the getInvS product
-      double pc[3];
-      Cx tr[3][3], det;
-      compCoord(P_, 0, cell, pc);
-      pmlTransform(pc, true, tr, det);
-      d[r] = toScalar(cmul(acc, det));
-      continue;
-    }
+    // (no PML 'volume' factor here: the reference compiles that block out, src/MxYeeFitMu.cpp:764-778 `#if 0`; only
+    //  the cell-averaged inverse permittivity carries det(invS), src/MxYeeFitInvEps.cpp:779-791)
     d[r] = muLossy_ ? toScalar(acc) : S(out);
   }
   return diagonal<S>(d);

@@ -920,9 +920,8 @@ class YeeSim:
                 out[r] = acc + complex((1.0 - sm) * (3.0 / 3.0), 0.0)
         if self.is_complex:
             out = out.astype(complex)
-        if self.pmls:                                          # the layer's 'volume', :765-777: det of the getInvS product
-            for r in range(len(P.gids)):
-                out[r] = out[r] * self._pml_transform(self.comp_coord(P, 0, P.cells[r]), True)[1]
+        # no PML 'volume' factor: the reference compiles that block out (src/MxYeeFitMu.cpp:764-778 is under `#if 0`);
+        # only inv_eps_vol_ave carries det(invS) (src/MxYeeFitInvEps.cpp:779-791)
         return sp.diags(out, format="csr")
 
     def inv_eps_vol_ave(self):
