@@ -4,9 +4,8 @@
 // AZ_conv = AZ_noscaled, i.e. the test is on the unscaled true residual 2-norm).
 //
 // Everything stays on the GPU; only scalars (dots, norms, the small Hessenberg) visit the
-// host.  GMRES uses classical Gram-Schmidt with re-orthogonalisation expressed as two fused
-// block products (mxg_mv_trans_mv / mxg_mv_times_mat), so one iteration costs two
-// reductions instead of j.  The ILU / AMG preconditioners of the reference are Trilinos
+// host.  The Krylov loops themselves (CG, BiCGStab, GMRES with CGS2 as two fused block products) are written on
+// the public ABI in mxg_krylov.h; this file adds the preconditioners, the multigrid cycle and the fused CG.  The ILU / AMG preconditioners of the reference are Trilinos
 // packages and are replaced by SpMV-only ones (Jacobi, Chebyshev polynomial): they change the
 // iteration count, not the converged answer.
 #include <algorithm>
@@ -15,27 +14,11 @@
 #include <vector>
 
 #include "mxg_internal.h"
+#include "mxg_krylov.h"
 
 namespace {
 
-typedef std::complex<double> cplx;
-
-struct Guard {  // frees temporaries on every exit path
-  std::vector<mxg_mv*> mvs;
-  ~Guard() { for (auto* v : mvs) mxg_mv_destroy(v); }
-  int make(mxg_ctx* c, int64_t n, int k, int cx, mxg_mv** out) {
-    int rc = mxg_mv_create(c, n, k, cx, out);
-    if (rc == 0) mvs.push_back(*out);
-    return rc;
-  }
-  int view(mxg_mv* p, int col0, int n, mxg_mv** out) {
-    std::vector<int> cols(n);
-    for (int i = 0; i < n; ++i) cols[i] = col0 + i;
-    int rc = mxg_mv_view(p, cols.data(), n, out);
-    if (rc == 0) mvs.push_back(*out);
-    return rc;
-  }
-};
+using mxg_krylov::true_residual;
 
 __global__ void k_jacobi(const double* __restrict__ diag, int w, long long n,
                          const double* __restrict__ r, double* __restrict__ z) {
@@ -69,13 +52,6 @@ int apply_prec(mxg_ctx* c, const mxg_csr* A, const mxg_solve_opts* o, const mxg_
     return mxg_mg_apply(c, o->mg, r, z);
   }
   return mxg_mv_copy(z, r);
-}
-
-int true_residual(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, const mxg_mv* x, mxg_mv* r,
-                  double* nrm) {
-  MXG_TRY(mxg_csr_apply(c, A, x, r));
-  MXG_TRY(mxg_mv_axpby(1.0, 0.0, b, -1.0, 0.0, r));   // r = b - A x
-  return mxg_mv_norm2(r, nrm);
 }
 
 
@@ -600,141 +576,23 @@ extern "C" int mxg_solve_cg(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_m
   MXG_CHECK(A->nrows == A->ncols_owned, "mxg_solve_cg: matrix must be square");
   MXG_CHECK(b->k == x->k && b->nlocal == A->nrows && x->nlocal == A->nrows,
             "mxg_solve_cg: shape mismatch");
-  const int cx = A->is_complex;
-  const int max_iters = o->max_iters > 0 ? o->max_iters : 100000;
-  info->iters = 0; info->converged = 1; info->true_res = 0.0;
-  Guard g;
-  mxg_mv *r, *z, *p, *q;
-  MXG_TRY(g.make(c, A->nrows, 1, cx, &r));
-  MXG_TRY(g.make(c, A->nrows, 1, cx, &z));
-  MXG_TRY(g.make(c, A->nrows, 1, cx, &p));
-  MXG_TRY(g.make(c, A->nrows, 1, cx, &q));
-  for (int col = 0; col < b->k; ++col) {
-    mxg_mv *bj, *xj;
-    MXG_TRY(g.view(const_cast<mxg_mv*>(b), col, 1, &bj));
-    MXG_TRY(g.view(x, col, 1, &xj));
-    double res = 0.0;
-    int it = 0;
-    if (cg_fused_ok(A, o)) {
-      MXG_TRY(mxg_ctx_reserve_reduce(c, 8));
-      MXG_TRY(cg_fused(c, const_cast<mxg_csr*>(A), o, bj, xj, r, z, p, q, max_iters, &it, &res));
-      info->iters += it;
-      if (res > info->true_res) info->true_res = res;
-      if (res > o->tol) info->converged = 0;
-      continue;
-    }
-    MXG_TRY(true_residual(c, A, bj, xj, r, &res));
-    // outer loop = the reference's `while (trueRes > linTol)` (src/MxMagWaveOp.cpp:876-885)
-    while (res > o->tol && it < max_iters) {
-      MXG_TRY(apply_prec(c, A, o, r, z));
-      MXG_TRY(mxg_mv_copy(p, z));
-      double rz[2];
-      MXG_TRY(mxg_mv_dot(r, z, rz));
-      double rnorm = res;
-      while (rnorm > o->tol && it < max_iters) {
-        MXG_TRY(mxg_csr_apply(c, A, p, q));
-        double pq[2];
-        MXG_TRY(mxg_mv_dot(p, q, pq));
-        if (pq[0] == 0.0) break;
-        const double alpha = rz[0] / pq[0];   // Hermitian A: both dots are real
-        MXG_TRY(mxg_mv_axpby(alpha, 0.0, p, 1.0, 0.0, xj));
-        MXG_TRY(mxg_mv_axpby(-alpha, 0.0, q, 1.0, 0.0, r));
-        ++it;
-        MXG_TRY(apply_prec(c, A, o, r, z));
-        double rz_new[2];
-        MXG_TRY(mxg_mv_dot(r, z, rz_new));
-        if (o->precond == 0) rnorm = sqrt(fabs(rz_new[0]));
-        else MXG_TRY(mxg_mv_norm2(r, &rnorm));
-        const double beta = rz_new[0] / rz[0];
-        rz[0] = rz_new[0];
-        MXG_TRY(mxg_mv_axpby(1.0, 0.0, z, beta, 0.0, p));
-      }
-      MXG_TRY(true_residual(c, A, bj, xj, r, &res));
-      if (rnorm > o->tol) break;  // stagnated or hit the cap: report what we have
-    }
-    info->iters += it;
-    if (res > info->true_res) info->true_res = res;
-    if (res > o->tol) info->converged = 0;
-  }
-  return 0;
+  // the Krylov loop itself is mxg_krylov.h (shared with the CPU backend of this ABI); the fused path is the GPU's own
+  return mxg_krylov::solve_cg(c, A, b, x, o, info,
+      [&](const mxg_mv* r, mxg_mv* z) { return apply_prec(c, A, o, r, z); },
+      [&](mxg_mv* bj, mxg_mv* xj, mxg_mv* r, mxg_mv* z, mxg_mv* p, mxg_mv* q, int max_iters, int* it, double* res) -> int {
+        if (!cg_fused_ok(A, o)) return -1;
+        MXG_TRY(mxg_ctx_reserve_reduce(c, 8));
+        return cg_fused(c, const_cast<mxg_csr*>(A), o, bj, xj, r, z, p, q, max_iters, it, res);
+      });
 }
 
-// AZ_bicgstab (src/MxMagWaveOp.cpp:333-334): right-preconditioned BiCGStab, short recurrences for the
-// non-symmetric operators (FIT inverse permittivity) - two products and two preconditioner applications per
-// iteration, no basis to orthogonalise against.  Stops on the unscaled true residual like the other solvers.
 extern "C" int mxg_solve_bicgstab(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
                                   const mxg_solve_opts* o, mxg_solve_info* info) {
   MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(A)));
   MXG_CHECK(c && A && b && x && o && info, "mxg_solve_bicgstab: NULL argument");
   MXG_CHECK(A->nrows == A->ncols_owned, "mxg_solve_bicgstab: matrix must be square");
   MXG_CHECK(b->k == x->k && b->nlocal == A->nrows && x->nlocal == A->nrows, "mxg_solve_bicgstab: shape mismatch");
-  const int cx = A->is_complex;
-  const int max_iters = o->max_iters > 0 ? o->max_iters : 100000;
-  info->iters = 0; info->converged = 1; info->true_res = 0.0;
-  Guard g;
-  mxg_mv *r, *rh, *p, *v, *y, *sv, *z, *t;
-  for (mxg_mv** w : {&r, &rh, &p, &v, &y, &sv, &z, &t}) MXG_TRY(g.make(c, A->nrows, 1, cx, w));
-  auto cdot = [&](const mxg_mv* a, const mxg_mv* bb, cplx* out) -> int {   // a^H b
-    double d[2] = {0.0, 0.0};
-    MXG_TRY(mxg_mv_dot(a, bb, d));
-    *out = cplx(d[0], cx ? d[1] : 0.0);
-    return 0;
-  };
-  for (int col = 0; col < b->k; ++col) {
-    mxg_mv *bj, *xj;
-    MXG_TRY(g.view(const_cast<mxg_mv*>(b), col, 1, &bj));
-    MXG_TRY(g.view(x, col, 1, &xj));
-    double res = 0.0;
-    MXG_TRY(true_residual(c, A, bj, xj, r, &res));
-    int it = 0;
-    while (res > o->tol && it < max_iters) {       // (re)start from the true residual
-      MXG_TRY(mxg_mv_copy(rh, r));
-      MXG_TRY(mxg_mv_fill(p, 0.0, 0.0));
-      MXG_TRY(mxg_mv_fill(v, 0.0, 0.0));
-      cplx rho = 1.0, alpha = 1.0, omega = 1.0;
-      double rnorm = res;
-      bool broke = false;
-      while (rnorm > o->tol && it < max_iters) {
-        cplx rho_new;
-        MXG_TRY(cdot(rh, r, &rho_new));
-        if (rho_new == cplx(0.0) || omega == cplx(0.0)) { broke = true; break; }
-        const cplx beta = (rho_new / rho) * (alpha / omega);
-        rho = rho_new;
-        // p = r + beta (p - omega v)
-        MXG_TRY(mxg_mv_axpby(-omega.real(), -omega.imag(), v, 1.0, 0.0, p));
-        MXG_TRY(mxg_mv_axpby(1.0, 0.0, r, beta.real(), beta.imag(), p));
-        MXG_TRY(apply_prec(c, A, o, p, y));
-        MXG_TRY(mxg_csr_apply(c, A, y, v));
-        cplx rhv;
-        MXG_TRY(cdot(rh, v, &rhv));
-        if (rhv == cplx(0.0)) { broke = true; break; }
-        alpha = rho / rhv;
-        MXG_TRY(mxg_mv_add(1.0, 0.0, r, -alpha.real(), -alpha.imag(), v, sv));      // s = r - alpha v
-        MXG_TRY(apply_prec(c, A, o, sv, z));
-        MXG_TRY(mxg_csr_apply(c, A, z, t));
-        cplx ts, tt;
-        MXG_TRY(cdot(t, sv, &ts));
-        MXG_TRY(cdot(t, t, &tt));
-        omega = tt == cplx(0.0) ? cplx(0.0) : ts / tt;
-        MXG_TRY(mxg_mv_axpby(alpha.real(), alpha.imag(), y, 1.0, 0.0, xj));         // x += alpha y + omega z
-        MXG_TRY(mxg_mv_axpby(omega.real(), omega.imag(), z, 1.0, 0.0, xj));
-        MXG_TRY(mxg_mv_add(1.0, 0.0, sv, -omega.real(), -omega.imag(), t, r));      // r = s - omega t
-        ++it;
-        MXG_TRY(mxg_mv_norm2(r, &rnorm));
-        if (!(rnorm == rnorm)) { broke = true; break; }
-      }
-      const double prev = res;
-      MXG_TRY(true_residual(c, A, bj, xj, r, &res));
-      if (!(res == res)) break;
-      if (broke && !(res < prev)) break;          // breakdown without progress: report what we have
-      if (!broke && rnorm > o->tol) break;        // iteration cap
-      if (!(res < prev) && res > o->tol) break;   // recurrence and true residual disagree, no progress
-    }
-    info->iters += it;
-    if (res > info->true_res) info->true_res = res;
-    if (!(res <= o->tol)) info->converged = 0;
-  }
-  return 0;
+  return mxg_krylov::solve_bicgstab(c, A, b, x, o, info, [&](const mxg_mv* r, mxg_mv* z) { return apply_prec(c, A, o, r, z); });
 }
 
 extern "C" int mxg_solve_gmres(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x,
@@ -744,105 +602,6 @@ extern "C" int mxg_solve_gmres(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mx
   MXG_CHECK(A->nrows == A->ncols_owned, "mxg_solve_gmres: matrix must be square");
   MXG_CHECK(b->k == x->k && b->nlocal == A->nrows && x->nlocal == A->nrows,
             "mxg_solve_gmres: shape mismatch");
-  const int cx = A->is_complex;
-  const int w = cx ? 2 : 1;
-  const int m = o->restart > 0 ? o->restart : 40;
-  const int max_iters = o->max_iters > 0 ? o->max_iters : 100000;
-  info->iters = 0; info->converged = 1; info->true_res = 0.0;
-  Guard g;
-  mxg_mv *V, *r, *z, *wv;
-  MXG_TRY(g.make(c, A->nrows, m + 1, cx, &V));
-  MXG_TRY(g.make(c, A->nrows, 1, cx, &r));
-  MXG_TRY(g.make(c, A->nrows, 1, cx, &z));
-  MXG_TRY(g.make(c, A->nrows, 1, cx, &wv));
-  std::vector<mxg_mv*> vcol(m + 1), vlead(m + 1);
-  for (int j = 0; j <= m; ++j) {
-    MXG_TRY(g.view(V, j, 1, &vcol[j]));
-    MXG_TRY(g.view(V, 0, j + 1, &vlead[j]));   // columns 0..j
-  }
-  std::vector<cplx> H((size_t)(m + 1) * m), cs(m), sn(m), gvec(m + 1), yv(m);
-  std::vector<double> hbuf((size_t)(m + 1) * w), h2buf((size_t)(m + 1) * w);
-  auto Hat = [&](int i, int j) -> cplx& { return H[(size_t)i + (size_t)(m + 1) * j]; };
-
-  for (int col = 0; col < b->k; ++col) {
-    mxg_mv *bj, *xj;
-    MXG_TRY(g.view(const_cast<mxg_mv*>(b), col, 1, &bj));
-    MXG_TRY(g.view(x, col, 1, &xj));
-    double res = 0.0;
-    MXG_TRY(true_residual(c, A, bj, xj, r, &res));
-    int it = 0;
-    while (res > o->tol && it < max_iters) {
-      // one restart cycle (right preconditioned: A M^-1 u = b, x = M^-1 u)
-      const double beta = res;
-      MXG_TRY(mxg_mv_copy(vcol[0], r));
-      MXG_TRY(mxg_mv_scale(vcol[0], 1.0 / beta, 0.0));
-      std::fill(gvec.begin(), gvec.end(), cplx(0.0));
-      gvec[0] = beta;
-      int j = 0;
-      double est = beta;
-      for (; j < m && it < max_iters; ++j) {
-        mxg_mv* zc;
-        MXG_TRY(prec_view(c, A, o, vcol[j], z, &zc));
-        MXG_TRY(mxg_csr_apply(c, A, zc, wv));
-        ++it;
-        // CGS2: h = V^H w; w -= V h; h2 = V^H w; w -= V h2; h += h2
-        MXG_TRY(mxg_mv_trans_mv(1.0, 0.0, vlead[j], wv, hbuf.data(), j + 1));
-        MXG_TRY(mxg_mv_times_mat(-1.0, 0.0, vlead[j], hbuf.data(), j + 1, j + 1, 1, 1.0, 0.0, wv));
-        MXG_TRY(mxg_mv_trans_mv(1.0, 0.0, vlead[j], wv, h2buf.data(), j + 1));
-        MXG_TRY(mxg_mv_times_mat(-1.0, 0.0, vlead[j], h2buf.data(), j + 1, j + 1, 1, 1.0, 0.0, wv));
-        for (int i = 0; i <= j; ++i)
-          Hat(i, j) = cx ? cplx(hbuf[2 * i] + h2buf[2 * i], hbuf[2 * i + 1] + h2buf[2 * i + 1])
-                         : cplx(hbuf[i] + h2buf[i], 0.0);
-        double hn;
-        MXG_TRY(mxg_mv_norm2(wv, &hn));
-        Hat(j + 1, j) = hn;
-        // previous rotations, then a new one to annihilate H(j+1, j)
-        for (int i = 0; i < j; ++i) {
-          cplx t = std::conj(cs[i]) * Hat(i, j) + std::conj(sn[i]) * Hat(i + 1, j);
-          Hat(i + 1, j) = -sn[i] * Hat(i, j) + cs[i] * Hat(i + 1, j);
-          Hat(i, j) = t;
-        }
-        {
-          const cplx a = Hat(j, j), bb = Hat(j + 1, j);
-          const double den = std::sqrt(std::norm(a) + std::norm(bb));
-          if (den == 0.0) { cs[j] = 1.0; sn[j] = 0.0; }
-          else { cs[j] = a / den; sn[j] = bb / den; }
-          Hat(j, j) = std::conj(cs[j]) * a + std::conj(sn[j]) * bb;
-          Hat(j + 1, j) = 0.0;
-          gvec[j + 1] = -sn[j] * gvec[j];
-          gvec[j] = std::conj(cs[j]) * gvec[j];
-        }
-        est = std::abs(gvec[j + 1]);
-        if (hn != 0.0 && j + 1 <= m) {
-          MXG_TRY(mxg_mv_copy(vcol[j + 1], wv));
-          MXG_TRY(mxg_mv_scale(vcol[j + 1], 1.0 / hn, 0.0));
-        }
-        if (est <= o->tol || hn == 0.0) { ++j; break; }
-      }
-      // solve the j x j triangular system and update x += M^-1 (V y)
-      const int jj = j;
-      for (int i = jj - 1; i >= 0; --i) {
-        cplx s = gvec[i];
-        for (int l = i + 1; l < jj; ++l) s -= Hat(i, l) * yv[l];
-        yv[i] = Hat(i, i) != cplx(0.0) ? s / Hat(i, i) : cplx(0.0);
-      }
-      if (jj > 0) {
-        for (int i = 0; i < jj; ++i) {
-          if (cx) { hbuf[2 * i] = yv[i].real(); hbuf[2 * i + 1] = yv[i].imag(); }
-          else hbuf[i] = yv[i].real();
-        }
-        MXG_TRY(mxg_mv_times_mat(1.0, 0.0, vlead[jj - 1], hbuf.data(), jj, jj, 1, 0.0, 0.0, wv));
-        mxg_mv* zc;
-        MXG_TRY(prec_view(c, A, o, wv, z, &zc));
-        MXG_TRY(mxg_mv_axpby(1.0, 0.0, zc, 1.0, 0.0, xj));
-      }
-      const double prev = res;
-      MXG_TRY(true_residual(c, A, bj, xj, r, &res));
-      if (jj == 0 || !(res < prev)) break;   // no progress: stop instead of spinning forever
-    }
-    info->iters += it;
-    if (res > info->true_res) info->true_res = res;
-    if (res > o->tol) info->converged = 0;
-  }
-  return 0;
+  return mxg_krylov::solve_gmres(c, A, b, x, o, info,
+      [&](mxg_mv* v, mxg_mv* z, mxg_mv** zc) { return prec_view(c, A, o, v, z, zc); });
 }
