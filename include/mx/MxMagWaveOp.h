@@ -77,6 +77,24 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
   MxMap const& getBMap() const { return *mBMap; }
   MxMap const& getPsiMap() const { return *mPsiMap; }
   RCP<MxCrsMatrix<Scalar> > getRhs() const { return mRhs; }
+  // Is the shifted vector Laplacian symmetric (Hermitian)?  With mirror-type boundary conditions (a PMC / PEC symmetry
+  // wall that keeps the on-wall component, src/MxGridField.cpp:157-188) the mirrored columns enter a boundary row with
+  // weight two and curlE is no longer curlB^T at the wall: P (L - sigma M)^-1 M is then not self-adjoint in any
+  // diagonal inner product and the Hermitian eigen-solver path must not be taken.  Two products with random vectors:
+  // |y^H A x - conj(x^H A y)| against |y||A x| (all-reduced on a decomposed grid).
+  bool isSelfAdjoint() const {
+    MxMultiVector<Scalar> x(mBMap, 1), y(mBMap, 1), ax(mBMap, 1), ay(mBMap, 1);
+    x.random(); y.random();
+    mShiftedVecLapl->apply(x, ax);
+    mShiftedVecLapl->apply(y, ay);
+    std::vector<Scalar> a(1), b(1);
+    std::vector<double> nx(1), nax(1);
+    ax.dot(y, a);                       // y^H A x
+    ay.dot(x, b);                       // x^H A y
+    y.norm2(nx); ax.norm2(nax);
+    const double diff = std::abs(a[0] - ScalarTraits<Scalar>::conjugate(b[0]));
+    return diff <= 1.0e-9 * nx[0] * nax[0];
+  }
   RCP<MxEMOps<DIM, Scalar> > getOps() const { return mEMOps; }
 
   void magToElec(MxMultiVector<Scalar> const& mag, MxMultiVector<Scalar>& elec) const {   // :1238-1250

@@ -54,7 +54,14 @@ class MxSolver {
     mInitVec = initVec;
     mEigProb = rcp(new Anasazi::BasicEigenproblem<Scalar, MV, OP>(op, mInitVec));
     mEigProb->setNEV(nev);
-    if (!sim->hasDielectric() && !sim->hasMu()) mEigProb->setHermitian(true);
+    // Hermitian path only for a pencil that really is symmetric: the reference calls setHermitian(true) whenever there
+    // is no dielectric (src/MxSolver.cpp:68-73), but symmetry walls that mirror the on-wall component (pmc lower walls
+    // of the octant problems, example/run.py) make the vector Laplacian non-symmetric at the wall, and a Hermitian
+    // Krylov-Schur on it stagnates at residuals of 1e-7 (tests/test_tm_term_gpu.py found it on the empty PEC sphere)
+    const bool hermitian = !sim->hasDielectric() && !sim->hasMu() && mwOp->isSelfAdjoint();
+    if (hermitian) mEigProb->setHermitian(true);
+    else if (!sim->hasDielectric() && !sim->hasMu() && myPID == 0 && verb)
+      std::cout << "MxSolver: the operator is not symmetric (mirror boundary conditions): general Krylov-Schur\n";
     // The reference iterates in the Euclidean inner product (src/MxSolver.cpp:69-75 never calls setM).  With mRhs = dmA
     // (or I) - a real positive diagonal - the shift-inverted operator is self-adjoint in the mRhs inner product when
     // there are no materials, which is what the Hermitian Krylov-Schur path needs; that inner product is kept for the
