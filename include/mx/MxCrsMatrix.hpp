@@ -211,6 +211,8 @@ class MxCrsMatrix {
   // host-side CSR (setup algebra, tests) and device handle (advanced usage)
   mx::Csr<Scalar> const& getHostCsr() const { return host(); }
   mxg_csr* getRawMatrix() const { ensureDevice(); return mDev; }
+  // never re-encode this matrix (operators outside the inner loops whose encoding pass would cost more than it saves)
+  void keepPlain() const { mNoCompress = true; }
   // the setup-time products / sums of real, single-rank matrices run on the GPU (MXH_DEVICE_CHAIN=0: on the host)
   static bool deviceChainEnabled() {
     static const bool on = !(getenv("MXH_DEVICE_CHAIN") && atoi(getenv("MXH_DEVICE_CHAIN")) == 0);
@@ -256,7 +258,8 @@ class MxCrsMatrix {
     return mHost;
   }
   void ensureDevice(bool compressIt = true) const {
-    static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
+    static const bool compressEnv = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
+    const bool compress = compressEnv && !mNoCompress;
     if (mDev) {
       if (compressIt && compress && !mCompressed && mRowMap->getNodeNumIndices() >= 256) {
         MX_ABI(mxg_csr_compress(mDev, NULL, NULL, NULL), "MxCrsMatrix (compress)");
@@ -439,7 +442,7 @@ class MxCrsMatrix {
   std::vector<std::vector<std::pair<MxIndex, Scalar> > > mRows;
   mutable mx::Csr<Scalar> mHost;     // (filled on demand for a matrix formed on the device: host())
   mutable bool mHostValid = true;
-  mutable bool mCompressed = false;
+  mutable bool mCompressed = false, mNoCompress = false;
   mutable std::atomic<int> mApplies{0};    // applies so far (a matrix may be applied from several rank threads)
   mutable mxg_csr* mDev;
 };

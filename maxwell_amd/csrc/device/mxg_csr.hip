@@ -752,6 +752,7 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
                               const int64_t* rowptr, const int32_t* colidx, const double* vals,
                               int is_complex, const mxg_halo_plan* plan, mxg_csr** out) {
   MXG_CHECK(c && rowptr && out, "mxg_csr_create: NULL argument");
+  MxgSetupTrace trace("mxg_csr_create (nnz)", rowptr[nrows]);
   MXG_CHECK(nrows >= 0 && ncols_owned >= 0 && nghost >= 0, "mxg_csr_create: negative size");
   MXG_CHECK(nrows < (int64_t)1 << 31 && ncols_owned + nghost < (int64_t)1 << 31,
             "mxg_csr_create: local sizes must fit int32 column / row-block indices");
@@ -855,6 +856,7 @@ int mxg_csr_adopt_device(mxg_ctx* c, int64_t nrows, int64_t ncols, int64_t nnz, 
 
 int mxg_csr_materialize(mxg_csr* a) {
   if (!a || !a->lazy) return 0;
+  MxgSetupTrace trace("mxg_csr_materialize (nnz)", a->nnz);
   a->lazy = 0;
   mxg_ctx* c = a->ctx;
   const int64_t nrows = a->nrows, nnz = a->nnz;
@@ -1158,6 +1160,7 @@ static int build_cs(mxg_csr* a, const int64_t* rp, const int32_t* ci, const doub
 extern "C" int mxg_csr_compress_from(mxg_csr* a, const int64_t* rowptr, const int32_t* colidx, const double* vals,
                                      int64_t* nblocks, int64_t* nfallback, int64_t* stream_bytes) {
   MXG_CHECK(a, "mxg_csr_compress: NULL argument");
+  MxgSetupTrace trace(rowptr ? "mxg_csr_compress_from (nnz)" : "mxg_csr_compress (nnz)", a->nnz);
   MXG_TRY(mxg_csr_materialize(a));
   mxg_ctx* c = a->ctx;
   MXG_HIP(hipSetDevice(c->device));

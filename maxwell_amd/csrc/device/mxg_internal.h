@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -223,6 +225,18 @@ int64_t mxg_tile_partials(const mxg_csr* a);
 int mxg_tile_launch(mxg_ctx* c, mxg_csr* a, const double* x, long long ldx, double* y, long long ldy, int k, int epi,
                     int dot, const double* xdot, double* partial, const double* rhs, const double* diag, double omega,
                     double beta, int halo, const double* xg, long long ldg);
+
+// MXG_TRACE_SETUP=1: wall time of the setup-side entry points on stderr (where do the seconds of solver setup go)
+struct MxgSetupTrace {
+  const char* what; long long n; std::chrono::steady_clock::time_point t0; bool on;
+  MxgSetupTrace(const char* w, long long n_) : what(w), n(n_), t0(std::chrono::steady_clock::now()) {
+    static const bool enabled = getenv("MXG_TRACE_SETUP") != nullptr;
+    on = enabled;
+  }
+  ~MxgSetupTrace() {
+    if (on) { hipDeviceSynchronize(); fprintf(stderr, "[mxg setup] %-28s %12lld  %.3f s\n", what, n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+  }
+};
 
 inline int mxg_grid_for(int64_t n, int block, int per_thread, int cap) {
   int64_t g = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);

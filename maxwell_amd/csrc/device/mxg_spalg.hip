@@ -223,6 +223,7 @@ int mxg_csr_adopt_device(mxg_ctx* c, int64_t nrows, int64_t ncols, int64_t nnz, 
 extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, mxg_csr** out) {
   MXG_TRY(check_operands(c, a, b, "mxg_csr_multiply"));
   MXG_CHECK(out, "mxg_csr_multiply: NULL argument");
+  MxgSetupTrace trace("mxg_csr_multiply (nnz a)", a->nnz);
   MXG_CHECK(a->ncols_owned == b->nrows, "mxg_csr_multiply: A has %lld columns, B has %lld rows", (long long)a->ncols_owned,
             (long long)b->nrows);
   MXG_HIP(hipSetDevice(c->device));
@@ -285,6 +286,7 @@ extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, 
 }
 
 extern "C" int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_csr* b, double sb, mxg_csr** out) {
+  MxgSetupTrace trace("mxg_csr_add (nnz a)", a->nnz);
   MXG_TRY(check_operands(c, a, b, "mxg_csr_add"));
   MXG_CHECK(out, "mxg_csr_add: NULL argument");
   MXG_CHECK(a->nrows == b->nrows && a->ncols_owned == b->ncols_owned, "mxg_csr_add: shapes differ");
@@ -314,6 +316,7 @@ extern "C" int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_cs
 }
 
 extern "C" int mxg_csr_purge(mxg_ctx* c, const mxg_csr* a, double tol, mxg_csr** out) {
+  MxgSetupTrace trace("mxg_csr_purge (nnz)", a->nnz);
   MXG_TRY(check_operands(c, a, a, "mxg_csr_purge"));
   MXG_CHECK(out, "mxg_csr_purge: NULL argument");
   MXG_HIP(hipSetDevice(c->device));
@@ -342,6 +345,7 @@ extern "C" int mxg_csr_purge(mxg_ctx* c, const mxg_csr* a, double tol, mxg_csr**
 
 // host copies of the CSR arrays (rowptr nrows + 1, colidx / vals nnz entries; NULL = not wanted)
 extern "C" int mxg_csr_download(const mxg_csr* a, int64_t* rowptr, int32_t* colidx, double* vals) {
+  MxgSetupTrace trace("mxg_csr_download (nnz)", a->nnz);
   MXG_CHECK(a, "mxg_csr_download: NULL argument");
   mxg_ctx* c = a->ctx;
   MXG_HIP(hipSetDevice(c->device));

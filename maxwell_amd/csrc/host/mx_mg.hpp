@@ -148,12 +148,13 @@ inline MgHierarchy buildAggregationHierarchy(const Csr<double>& A0, const UVec<i
 // host + device hierarchy in one object (defined in mxh_mg.cpp; C handle type of mxh.h)
 struct mxh_mg;
 struct mxg_ctx;
+struct mxg_csr;
 namespace mx { struct YeeField; }
 mxh_mg* mxh_mg_build(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::YeeField& F, const int n[3],
                      int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
-                     double coarse_scale);
+                     double coarse_scale, mxg_csr* A0dev = nullptr);
 // same for any set of lattice unknowns given by their global ids (the owned block of one rank of a decomposed grid)
 mxh_mg* mxh_mg_build_gids(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::UVec<int64_t>& gids, int ncomp, const int n[3],
                           int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
-                          double coarse_scale);
+                          double coarse_scale, mxg_csr* A0dev = nullptr);
 #endif

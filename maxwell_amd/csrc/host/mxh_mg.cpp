@@ -11,20 +11,24 @@ struct mxh_mg {
   std::vector<mxg_csr*> A, P, R;
   std::vector<int64_t> rows, nnz;
   mxg_mg* mg = nullptr;
+  bool ownsA0 = true;                  // level 0 may be the caller's device matrix (not copied, not destroyed here)
   ~mxh_mg() {
     if (mg) mxg_mg_destroy(mg);
-    for (auto* m : A) mxg_csr_destroy(m);
+    for (size_t l = ownsA0 ? 0 : 1; l < A.size(); ++l) mxg_csr_destroy(A[l]);
     for (auto* m : P) mxg_csr_destroy(m);
     for (auto* m : R) mxg_csr_destroy(m);
   }
 };
 
-static mxg_csr* upload(mxg_ctx* ctx, const mx::Csr<double>& m) {
+// reencode: level operators take the tile form / compressed stream (their products carry the fused smoother
+// epilogues); the transfer operators never use either - the piecewise-constant prolongation runs from its injection
+// form, the restriction from its ELL form (mxg_csr.hip) - and planning them cost 0.9 s of the 256^3 setup
+static mxg_csr* upload(mxg_ctx* ctx, const mx::Csr<double>& m, bool reencode) {
   mxg_csr* d = nullptr;
   if (mxg_csr_create(ctx, m.nrows, m.ncols, 0, m.rowptr.data(), m.col.data(), m.val.data(), 0, nullptr, &d) != 0)
     throw std::runtime_error(std::string("mxg_csr_create: ") + mxg_last_error());
   static const bool compress = !(getenv("MXG_COMPRESS") && atoi(getenv("MXG_COMPRESS")) == 0);
-  if (compress && m.nrows >= 256 &&    // small levels too: their sweeps are launch-bound, the fused epilogues halve the launches
+  if (reencode && compress && m.nrows >= 256 &&    // small levels too: their sweeps are launch-bound, the fused epilogues halve the launches
       mxg_csr_compress_from(d, m.rowptr.data(), m.col.data(), m.val.data(), nullptr, nullptr, nullptr) != 0)
     throw std::runtime_error(std::string("mxg_csr_compress: ") + mxg_last_error());
   return d;
@@ -32,19 +36,26 @@ static mxg_csr* upload(mxg_ctx* ctx, const mx::Csr<double>& m) {
 
 mxh_mg* mxh_mg_build(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::YeeField& F, const int n[3],
                      int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
-                     double coarse_scale) {
-  return mxh_mg_build_gids(ctx, A0, F.gids, F.ncomp, n, min_coarse, max_levels, sweeps, coarse_sweeps, omega, coarse_scale);
+                     double coarse_scale, mxg_csr* A0dev) {
+  return mxh_mg_build_gids(ctx, A0, F.gids, F.ncomp, n, min_coarse, max_levels, sweeps, coarse_sweeps, omega, coarse_scale, A0dev);
 }
 
+// A0dev: the caller's device copy of A0 (already re-encoded) serves as level 0 and stays the caller's: the 256^3
+// operator is 2.2 GB and its upload + tile plan 0.3 s
 mxh_mg* mxh_mg_build_gids(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::UVec<int64_t>& gids, int ncomp, const int n[3],
                           int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
-                          double coarse_scale) {
+                          double coarse_scale, mxg_csr* A0dev) {
   mx::MgHierarchy h = mx::buildAggregationHierarchy(A0, gids, ncomp, n, min_coarse, max_levels);
   std::unique_ptr<mxh_mg> g(new mxh_mg());
   g->ctx = ctx;
-  for (auto& m : h.A) { g->A.push_back(upload(ctx, m)); g->rows.push_back(m.nrows); g->nnz.push_back(m.nnz()); }
-  for (auto& m : h.P) g->P.push_back(upload(ctx, m));
-  for (auto& m : h.R) g->R.push_back(upload(ctx, m));
+  g->ownsA0 = A0dev == nullptr;
+  for (size_t l = 0; l < h.A.size(); ++l) {
+    const mx::Csr<double>& m = h.A[l];
+    g->A.push_back(l == 0 && A0dev ? A0dev : upload(ctx, m, true));
+    g->rows.push_back(m.nrows); g->nnz.push_back(m.nnz());
+  }
+  for (auto& m : h.P) g->P.push_back(upload(ctx, m, false));
+  for (auto& m : h.R) g->R.push_back(upload(ctx, m, false));
   if (mxg_mg_create(ctx, (int)g->A.size(), g->A.data(), g->P.data(), g->R.data(), sweeps, sweeps, coarse_sweeps,
                     omega, coarse_scale, &g->mg) != 0)
     throw std::runtime_error(std::string("mxg_mg_create: ") + mxg_last_error());
