@@ -106,7 +106,8 @@ int mxg_csr_destroy(mxg_csr* a);
  *                            MxUtil::Trilinos::massiveCrsMultiply, src/MxUtil.cpp:318-371)
  *   add:      C = sa A + sb B MxCrsMatrix::matrixMatrixAdd (src/MxCrsMatrix.cpp:404-457; setShift, src/MxMagWaveOp.cpp:248-255)
  *   purge:    keep |a| > tol MxCrsMatrix::purgeZeros (src/MxCrsMatrix.cpp:84-116)
- * The result is a new matrix owned by the caller (mxg_csr_destroy).  download copies the CSR arrays to the host
+ * Operands: columns ascending and unique inside every row (what fillComplete leaves; the diagonal-factor fast path of
+ * multiply copies the other factor's pattern as it stands).  The result is a new matrix owned by the caller (mxg_csr_destroy).  download copies the CSR arrays to the host
  * (NULL = not wanted): MxCrsMatrix::getLocalRow / save and the multigrid setup read them. */
 int mxg_csr_multiply(mxg_ctx* ctx, const mxg_csr* a, const mxg_csr* b, mxg_csr** out);
 int mxg_csr_add(mxg_ctx* ctx, const mxg_csr* a, double sa, const mxg_csr* b, double sb, mxg_csr** out);

@@ -188,20 +188,36 @@ __global__ void k_is_diagonal(const long long* __restrict__ rp, const int* __res
   if (rp[i + 1] - rp[i] != 1 || ci[rp[i]] != i) *flag = 0;
 }
 
+// device temporaries of one call: freed on every exit path (an allocation failure at 256^3 / 512^3 used to leak the GBs
+// already allocated); keep() hands a finished array over to the result matrix
+struct DevPool {
+  std::vector<void*> p;
+  ~DevPool() { for (void* q : p) hipFree(q); }
+  template <typename T>
+  int alloc(T** out, size_t bytes) {
+    void* q = nullptr;
+    MXG_HIP(hipMalloc(&q, bytes));
+    p.push_back(q);
+    *out = static_cast<T*>(q);
+    return 0;
+  }
+  void keep(void* q) { p.erase(std::remove(p.begin(), p.end(), q), p.end()); }
+};
+
 inline unsigned rows_grid(long long nrows) { return (unsigned)std::max<long long>((nrows + SA_BLOCK - 1) / SA_BLOCK, 1); }
 
 int is_diagonal(mxg_ctx* c, const mxg_csr* a, bool* out) {
+  DevPool pool;
   *out = false;
   if (a->nrows != a->ncols_owned + a->nghost || a->nnz != a->nrows) return 0;
   int* d_flag = nullptr;
   int h = 1;
-  MXG_HIP(hipMalloc(&d_flag, sizeof(int)));
+  MXG_TRY(pool.alloc(&d_flag, sizeof(int)));
   MXG_HIP(hipMemcpyAsync(d_flag, &h, sizeof(int), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_is_diagonal, dim3(rows_grid(a->nrows)), dim3(SA_BLOCK), 0, c->stream,
                      (const long long*)a->d_rowptr, (const int*)a->d_colidx, (long long)a->nrows, d_flag);
   MXG_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MXG_HIP(hipStreamSynchronize(c->stream));
-  hipFree(d_flag);
   *out = h != 0;
   return 0;
 }
@@ -221,6 +237,7 @@ int mxg_csr_adopt_device(mxg_ctx* c, int64_t nrows, int64_t ncols, int64_t nnz, 
                          double* d_vals, mxg_csr** out);
 
 extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, mxg_csr** out) {
+  DevPool pool;
   MXG_TRY(check_operands(c, a, b, "mxg_csr_multiply"));
   MXG_CHECK(out, "mxg_csr_multiply: NULL argument");
   MxgSetupTrace trace("mxg_csr_multiply (nnz a)", a->nnz);
@@ -235,9 +252,9 @@ extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, 
     // a diagonal factor: the other factor's pattern, each value one product (what the general loop would form)
     const mxg_csr* pat = adiag ? b : a;
     int64_t* rp = nullptr; int32_t* ci = nullptr; double* va = nullptr;
-    MXG_HIP(hipMalloc(&rp, sizeof(int64_t) * (pat->nrows + 1)));
-    MXG_HIP(hipMalloc(&ci, sizeof(int32_t) * (pat->nnz + 8)));
-    MXG_HIP(hipMalloc(&va, sizeof(double) * (pat->nnz + 8)));
+    MXG_TRY(pool.alloc(&rp, sizeof(int64_t) * (pat->nrows + 1)));
+    MXG_TRY(pool.alloc(&ci, sizeof(int32_t) * (pat->nnz + 8)));
+    MXG_TRY(pool.alloc(&va, sizeof(double) * (pat->nnz + 8)));
     MXG_HIP(hipMemsetAsync(ci, 0, sizeof(int32_t) * (pat->nnz + 8), c->stream));
     MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (pat->nnz + 8), c->stream));
     MXG_HIP(hipMemcpyAsync(rp, pat->d_rowptr, sizeof(int64_t) * (pat->nrows + 1), hipMemcpyDeviceToDevice, c->stream));
@@ -249,43 +266,45 @@ extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, 
       hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)std::min<long long>((pat->nnz + SA_BLOCK - 1) / SA_BLOCK, 65535)), dim3(SA_BLOCK), 0,
                          c->stream, (const int*)a->d_colidx, (const double*)a->d_vals, (const double*)b->d_vals, (long long)a->nnz, va);
     MXG_HIP(hipGetLastError());
-    return mxg_csr_adopt_device(c, pat->nrows, adiag ? b->ncols_owned : b->ncols_owned, pat->nnz, rp, ci, va, out);
+    pool.keep(rp); pool.keep(ci); pool.keep(va);
+  return mxg_csr_adopt_device(c, pat->nrows, adiag ? b->ncols_owned : b->ncols_owned, pat->nnz, rp, ci, va, out);
   }
   long long *ub_cnt = nullptr, *ub = nullptr, *cnt = nullptr;
-  MXG_HIP(hipMalloc(&ub_cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
-  MXG_HIP(hipMalloc(&ub, sizeof(long long) * (nrows + 1)));
-  MXG_HIP(hipMalloc(&cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
+  MXG_TRY(pool.alloc(&ub_cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
+  MXG_TRY(pool.alloc(&ub, sizeof(long long) * (nrows + 1)));
+  MXG_TRY(pool.alloc(&cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
   hipLaunchKernelGGL(k_mm_upper, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
                      (const int*)a->d_colidx, (const long long*)b->d_rowptr, nrows, ub_cnt);
   MXG_TRY(exclusive_scan(c, ub_cnt, nrows, ub));
   long long total = 0;
   MXG_HIP(hipMemcpy(&total, ub + nrows, sizeof(long long), hipMemcpyDeviceToHost));
   int* tc = nullptr; double* tv = nullptr;
-  MXG_HIP(hipMalloc(&tc, sizeof(int) * std::max<long long>(total, 1)));
-  MXG_HIP(hipMalloc(&tv, sizeof(double) * std::max<long long>(total, 1)));
+  MXG_TRY(pool.alloc(&tc, sizeof(int) * std::max<long long>(total, 1)));
+  MXG_TRY(pool.alloc(&tv, sizeof(double) * std::max<long long>(total, 1)));
   hipLaunchKernelGGL(k_mm_rows, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
                      (const int*)a->d_colidx, (const double*)a->d_vals, (const long long*)b->d_rowptr, (const int*)b->d_colidx,
                      (const double*)b->d_vals, nrows, (const long long*)ub, tc, tv, cnt);
   MXG_HIP(hipGetLastError());
   int64_t* rp = nullptr;
-  MXG_HIP(hipMalloc(&rp, sizeof(int64_t) * (nrows + 1)));
+  MXG_TRY(pool.alloc(&rp, sizeof(int64_t) * (nrows + 1)));
   MXG_TRY(exclusive_scan(c, cnt, nrows, (long long*)rp));
   long long nnz = 0;
   MXG_HIP(hipMemcpy(&nnz, rp + nrows, sizeof(long long), hipMemcpyDeviceToHost));
   int32_t* ci = nullptr; double* va = nullptr;
-  MXG_HIP(hipMalloc(&ci, sizeof(int32_t) * (nnz + 8)));
-  MXG_HIP(hipMalloc(&va, sizeof(double) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&ci, sizeof(int32_t) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8)));
   MXG_HIP(hipMemsetAsync(ci, 0, sizeof(int32_t) * (nnz + 8), c->stream));
   MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8), c->stream));
   hipLaunchKernelGGL(k_compact, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)ub, (const int*)tc,
                      (const double*)tv, nrows, (const long long*)rp, ci, va);
   MXG_HIP(hipGetLastError());
   MXG_HIP(hipStreamSynchronize(c->stream));
-  hipFree(ub_cnt); hipFree(ub); hipFree(cnt); hipFree(tc); hipFree(tv);
+  pool.keep(rp); pool.keep(ci); pool.keep(va);
   return mxg_csr_adopt_device(c, nrows, b->ncols_owned, nnz, rp, ci, va, out);
 }
 
 extern "C" int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_csr* b, double sb, mxg_csr** out) {
+  DevPool pool;
   MxgSetupTrace trace("mxg_csr_add (nnz a)", a->nnz);
   MXG_TRY(check_operands(c, a, b, "mxg_csr_add"));
   MXG_CHECK(out, "mxg_csr_add: NULL argument");
@@ -293,17 +312,17 @@ extern "C" int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_cs
   MXG_HIP(hipSetDevice(c->device));
   const long long nrows = a->nrows;
   long long* cnt = nullptr;
-  MXG_HIP(hipMalloc(&cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
+  MXG_TRY(pool.alloc(&cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
   hipLaunchKernelGGL(k_add_count, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
                      (const int*)a->d_colidx, (const long long*)b->d_rowptr, (const int*)b->d_colidx, nrows, cnt);
   int64_t* rp = nullptr;
-  MXG_HIP(hipMalloc(&rp, sizeof(int64_t) * (nrows + 1)));
+  MXG_TRY(pool.alloc(&rp, sizeof(int64_t) * (nrows + 1)));
   MXG_TRY(exclusive_scan(c, cnt, nrows, (long long*)rp));
   long long nnz = 0;
   MXG_HIP(hipMemcpy(&nnz, rp + nrows, sizeof(long long), hipMemcpyDeviceToHost));
   int32_t* ci = nullptr; double* va = nullptr;
-  MXG_HIP(hipMalloc(&ci, sizeof(int32_t) * (nnz + 8)));
-  MXG_HIP(hipMalloc(&va, sizeof(double) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&ci, sizeof(int32_t) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8)));
   MXG_HIP(hipMemsetAsync(ci, 0, sizeof(int32_t) * (nnz + 8), c->stream));
   MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8), c->stream));
   hipLaunchKernelGGL(k_add_fill, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
@@ -311,35 +330,36 @@ extern "C" int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_cs
                      (const int*)b->d_colidx, (const double*)b->d_vals, sb, nrows, (const long long*)rp, ci, va);
   MXG_HIP(hipGetLastError());
   MXG_HIP(hipStreamSynchronize(c->stream));
-  hipFree(cnt);
+  pool.keep(rp); pool.keep(ci); pool.keep(va);
   return mxg_csr_adopt_device(c, nrows, a->ncols_owned, nnz, rp, ci, va, out);
 }
 
 extern "C" int mxg_csr_purge(mxg_ctx* c, const mxg_csr* a, double tol, mxg_csr** out) {
+  DevPool pool;
   MxgSetupTrace trace("mxg_csr_purge (nnz)", a->nnz);
   MXG_TRY(check_operands(c, a, a, "mxg_csr_purge"));
   MXG_CHECK(out, "mxg_csr_purge: NULL argument");
   MXG_HIP(hipSetDevice(c->device));
   const long long nrows = a->nrows;
   long long* cnt = nullptr;
-  MXG_HIP(hipMalloc(&cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
+  MXG_TRY(pool.alloc(&cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
   hipLaunchKernelGGL(k_purge_count, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
                      (const double*)a->d_vals, tol, nrows, cnt);
   int64_t* rp = nullptr;
-  MXG_HIP(hipMalloc(&rp, sizeof(int64_t) * (nrows + 1)));
+  MXG_TRY(pool.alloc(&rp, sizeof(int64_t) * (nrows + 1)));
   MXG_TRY(exclusive_scan(c, cnt, nrows, (long long*)rp));
   long long nnz = 0;
   MXG_HIP(hipMemcpy(&nnz, rp + nrows, sizeof(long long), hipMemcpyDeviceToHost));
   int32_t* ci = nullptr; double* va = nullptr;
-  MXG_HIP(hipMalloc(&ci, sizeof(int32_t) * (nnz + 8)));
-  MXG_HIP(hipMalloc(&va, sizeof(double) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&ci, sizeof(int32_t) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8)));
   MXG_HIP(hipMemsetAsync(ci, 0, sizeof(int32_t) * (nnz + 8), c->stream));
   MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8), c->stream));
   hipLaunchKernelGGL(k_purge_fill, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
                      (const int*)a->d_colidx, (const double*)a->d_vals, tol, nrows, (const long long*)rp, ci, va);
   MXG_HIP(hipGetLastError());
   MXG_HIP(hipStreamSynchronize(c->stream));
-  hipFree(cnt);
+  pool.keep(rp); pool.keep(ci); pool.keep(va);
   return mxg_csr_adopt_device(c, nrows, a->ncols_owned, nnz, rp, ci, va, out);
 }
 

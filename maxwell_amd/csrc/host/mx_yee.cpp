@@ -1224,9 +1224,13 @@ std::map<std::string, Csr<S>> YeeAssembler<S>::singleOps() const {   // MxEMOps:
 }
 
 template <typename S>
-std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps() const {   // src/MxMagWaveOp.cpp:138-245
+std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps() const { return waveOps(singleOps()); }
+
+// the operator chain from primitives the caller already holds (a sim created in device-chain mode keeps singleOps():
+// forming the host chain later must not assemble every Yee / Dey-Mittra / invEps primitive a second time)
+template <typename S>
+std::map<std::string, Csr<S>> YeeAssembler<S>::waveOps(std::map<std::string, Csr<S>> o) const {   // src/MxMagWaveOp.cpp:138-245
   Tick tick;
-  std::map<std::string, Csr<S>> o = singleOps();
   const bool pec = hasPec();
   const bool diel = hasDielectric();
   tick("primitives");

@@ -137,6 +137,7 @@ class YeeAssembler {
 
   // name -> matrix: curlE curlB divB gradPsi [dmA dmL dmVInv] curlCurl gradDiv vecLapl scaLapl mRhs
   std::map<std::string, Csr<S>> waveOps() const;
+  std::map<std::string, Csr<S>> waveOps(std::map<std::string, Csr<S>> singles) const;   // chain from given primitives
   // the single Yee operators only (the products are then formed elsewhere: on the device, MXH_DEVICE_CHAIN)
   std::map<std::string, Csr<S>> singleOps() const;
   // massiveCrsMultiply order: first name applied first, m_k * (... * (m_1 * m_0))

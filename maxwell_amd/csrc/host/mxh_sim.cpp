@@ -1,4 +1,5 @@
 // C ABI over the host-side assembler (include/mxh.h, mxh_sim_*).
+#include <mutex>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -218,8 +219,14 @@ static int exportCsr(const mx::Csr<double>& m, int64_t* nrows, int64_t* ncols, i
 
 // the host chain of a sim created in device-chain mode, on first demand
 void mxh_sim_ensure_chain(mxh_sim* s) {
+  static std::mutex mu;                       // rank threads of an in-process world may share a sim
+  std::lock_guard<std::mutex> lk(mu);
   if (s->chain_ready) return;
-  std::map<std::string, mx::Csr<double> > full = s->asmb->waveOps();
+  // from the primitives the sim already holds (device-chain mode keeps singleOps()): nothing is assembled twice
+  std::map<std::string, mx::Csr<double> > singles;
+  for (const char* nm : {"curlE", "curlB", "divB", "gradPsi", "dmA", "dmL", "dmVInv", "invEps", "invEpsVolAve", "mu", "invMuVolAve"})
+    if (s->ops.count(nm)) singles[nm] = s->ops.at(nm);
+  std::map<std::string, mx::Csr<double> > full = singles.count("curlE") ? s->asmb->waveOps(std::move(singles)) : s->asmb->waveOps();
   for (auto& kv : full) if (!s->ops.count(kv.first)) s->ops[kv.first] = std::move(kv.second);
   s->chain_ready = true;
 }
