@@ -156,6 +156,7 @@ struct mxg_csr {
   // (row blocks, diagonal, pipeline descriptors) only when something applies / compresses it: the intermediates of the
   // operator chain never do (mxg_csr_materialize)
   int lazy = 0;
+  int small_maxlen = -1;                // longest row, computed on demand for small matrices (mxg_solve.hip: one-workgroup smoother)
   // tile form (mxg_tile.hip): wavefront-uniform tiles of short (A: <= 8 entries) and long (B: 9..16) patterns, the
   // irregular rows as ELL groups of 64 rows (ghost-free groups first) and rows of more than 40 entries as "long rows"
   int tile_on = 0, tile_tried = 0;      // tile_tried: mxg_tile_build has looked at this matrix (it may have declined: coverage)

@@ -195,6 +195,73 @@ __global__ void k_cheb_step(long long n, const double* __restrict__ diag, double
   }
 }
 
+// The whole Chebyshev iteration of a SMALL level (the coarsest: ~1 000 rows of <= 16 entries) in ONE workgroup: every
+// thread keeps its two rows of the matrix in registers, the iterates live in LDS, a step is a barrier instead of a launch
+// (16 launches of ~7 us each were 7 % of the 256^3 eigen-solve; walking the CSR arrays from L2 inside the workgroup was
+// no faster than the launches - the row walks are dependent loads).  Same arithmetic as the fused epilogues (row sums in
+// storage order, the step formulas of EPI 5 / 4), from a zero guess: identical iterates.
+constexpr int CHEB_SMALL_ROWS = 2048, CHEB_SMALL_STEPS = 32, CHEB_SMALL_LEN = 16;
+struct ChebCoef { double omega[CHEB_SMALL_STEPS], beta[CHEB_SMALL_STEPS]; };
+__global__ __launch_bounds__(1024) void k_cheb_small(const long long* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                      const double* __restrict__ vals, const double* __restrict__ diag, int n,
+                                                      const double* __restrict__ r, double* __restrict__ zout, int sweeps,
+                                                      const ChebCoef cf) {
+  __shared__ double za[CHEB_SMALL_ROWS], zb[CHEB_SMALL_ROWS];
+  double* z = za;
+  double* t = zb;
+  int cc[2][CHEB_SMALL_LEN], len[2];
+  double vv[2][CHEB_SMALL_LEN], dg[2], rr[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int row = threadIdx.x + 1024 * k;
+    len[k] = 0; dg[k] = 0.0; rr[k] = 0.0;
+    long long q0 = 0;
+    if (row < n) { q0 = rowptr[row]; len[k] = (int)(rowptr[row + 1] - q0); dg[k] = diag[row]; rr[k] = r[row]; }
+#pragma unroll
+    for (int i = 0; i < CHEB_SMALL_LEN; ++i) {
+      cc[k][i] = i < len[k] ? colidx[q0 + i] : 0;
+      vv[k][i] = i < len[k] ? vals[q0 + i] : 0.0;
+    }
+    if (row < n) z[row] = dg[k] != 0.0 ? cf.omega[0] * rr[k] / dg[k] : 0.0;
+  }
+  __syncthreads();
+  for (int s = 1; s < sweeps; ++s) {
+    const double omega = cf.omega[s], beta = cf.beta[s];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = threadIdx.x + 1024 * k;
+      if (row < n) {
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < CHEB_SMALL_LEN; ++i) {
+          const double s2 = sum + vv[k][i] * z[cc[k][i]];
+          sum = i < len[k] ? s2 : sum;
+        }
+        const double d = dg[k], zi = z[row];
+        const double prev = s == 1 ? 0.0 : t[row];                  // the iterate before z (zero after the first step)
+        t[row] = d != 0.0 ? (s == 1 ? zi + beta * zi + omega * (rr[k] - sum) / d : zi + beta * (zi - prev) + omega * (rr[k] - sum) / d) : zi;
+      }
+    }
+    __syncthreads();
+    double* w = z; z = t; t = w;
+  }
+  for (int i = threadIdx.x; i < n; i += 1024) zout[i] = z[i];
+}
+
+// longest row of a small matrix (cached in the handle; the row pointers of <= CHEB_SMALL_ROWS rows are 16 KiB)
+int small_max_row_len(mxg_ctx* c, mxg_csr* A, int* out) {
+  if (A->small_maxlen < 0) {
+    std::vector<long long> rp((size_t)A->nrows + 1);
+    MXG_HIP(hipMemcpyAsync(rp.data(), A->d_rowptr, sizeof(long long) * (A->nrows + 1), hipMemcpyDeviceToHost, c->stream));
+    MXG_HIP(hipStreamSynchronize(c->stream));
+    long long m = 0;
+    for (long long r2 = 0; r2 < A->nrows; ++r2) m = std::max(m, rp[r2 + 1] - rp[r2]);
+    A->small_maxlen = (int)std::min<long long>(m, 1 << 30);
+  }
+  *out = A->small_maxlen;
+  return 0;
+}
+
 // `sweeps` steps of the Chebyshev iteration for D^-1 A on [lmax / ratio, lmax] (Saad, Iterative Methods, Alg. 12.1)
 int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio) {
   mxg_ctx* c = mg->ctx;
@@ -204,6 +271,24 @@ int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio)
   const double lmax = mg->lmax[l], lmin = lmax / ratio;
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma1 = theta / delta;
   double rho = 1.0 / sigma1;
+  static const bool small_kernel = !(getenv("MXG_MG_SMALL_KERNEL") && atoi(getenv("MXG_MG_SMALL_KERNEL")) == 0);
+  int maxlen = CHEB_SMALL_LEN + 1;
+  if (small_kernel && zero_guess && sweeps >= 2 && sweeps <= CHEB_SMALL_STEPS && n <= CHEB_SMALL_ROWS && n > 0 && !A->is_complex &&
+      A->nghost == 0 && A->nneigh == 0)
+    MXG_TRY(small_max_row_len(c, A, &maxlen));
+  if (maxlen <= CHEB_SMALL_LEN) {
+    ChebCoef cf;
+    double rh = rho;
+    for (int s = 0; s < sweeps; ++s) {
+      if (s == 0) { cf.omega[0] = 1.0 / theta; cf.beta[0] = 0.0; }
+      else { const double rn = 1.0 / (2.0 * sigma1 - rh); cf.omega[s] = 2.0 * rn / delta; cf.beta[s] = rn * rh; rh = rn; }
+    }
+    hipLaunchKernelGGL(k_cheb_small, dim3(1), dim3(1024), 0, c->stream, (const long long*)A->d_rowptr, (const int*)A->d_colidx,
+                       (const double*)A->d_vals, (const double*)A->d_diag, (int)n, (const double*)mg->r[l]->colptr(0),
+                       mg->z[l]->colptr(0), sweeps, cf);
+    MXG_HIP(hipGetLastError());
+    return 0;
+  }
   bool prev_zero = false;             // the previous iterate is the zero guess: nothing to read
   for (int s = 0; s < sweeps; ++s) {
     double omega, beta;
