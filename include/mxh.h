@@ -63,6 +63,11 @@ int mxh_owner_of_cell(const int n[3], const int proc_grid[3], const int cell[3])
 int mxh_sim_create_box(const int n[3], const double origin[3], const double size[3],
                        const char* const lower[3], const char* const upper[3], const char* pec_shape,
                        int strict, const int box_lo[3], const int box_hi[3], mxh_sim** out);
+/* The operator chain (curlCurl, gradDiv, vecLapl, scaLapl, mRhs: MxMagWaveOp::initMatrices, src/MxMagWaveOp.cpp:138-245)
+ * of a sim that so far holds only its single operators, formed on the GPU of `ctx` (mxg_csr_multiply / add / purge,
+ * bit-identical to the host chain) and read back.  mxh_solver_create calls it for the box + halo window of a rank of a
+ * decomposed grid; a no-op once the chain exists.  Real problems. */
+int mxh_sim_device_chain(mxg_ctx* ctx, mxh_sim* s);
 /* owned rows of a named operator (or of vecLapl - shift*mRhs when name == "shifted") with GLOBAL
  * column ids: the row-partitioned form Epetra would hold.  row_gids / col_field_owned_gids are the
  * ascending global ids of the owned row entries and of the owned entries of the column field. */

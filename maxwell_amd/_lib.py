@@ -127,6 +127,7 @@ MXH_SIGNATURES = {
     "mxh_dist_ops_matrix": (C.c_int, [vp, C.c_char_p, C.c_double, C.POINTER(vp), c_i64p, C.POINTER(c_i64p), c_i64p,
                                       C.POINTER(c_i64p), c_i64p]),
     "mxh_dist_ops_destroy": (C.c_int, [vp]),
+    "mxh_sim_device_chain": (C.c_int, [vp, vp]),
     "mxh_sim_dist_op": (C.c_int, [vp, C.c_char_p, C.c_double, c_i64p, c_i64p, C.POINTER(c_i64p),
                                   C.POINTER(c_i64p), C.POINTER(c_dp), C.POINTER(c_i64p), c_i64p,
                                   C.POINTER(c_i64p), c_ip]),

@@ -448,6 +448,11 @@ class Sim:
         val = np.ctypeslib.as_array(va, (max(nz, 1),))[:nz].copy()
         return sp.csr_matrix((val, col, rowptr), shape=(nr, nc))
 
+    def form_chain_on_device(self, ctx):
+        """Form the operator chain (curlCurl, gradDiv, vecLapl, scaLapl, mRhs) on the GPU of `ctx` and read it back
+        (mxh_sim_device_chain); what mxh_solver_create does for the window of a rank of a decomposed grid."""
+        _chk(self.lib.mxh_sim_device_chain(ctx.h, self.h), self.lib, "mxh")
+
     def to_device(self, ctx, name, shift=None):
         nr, nc, nz, rp, ci, va = self.op_raw(name, shift)
         return CsrMatrix(ctx, nr, nc, C.cast(rp, C.c_void_p), C.cast(ci, C.c_void_p),

@@ -166,7 +166,14 @@ extern "C" int mxh_problem_solver(mxg_ctx* ctx, mxh_problem* p, int verbose, mxh
       int pg[3];
       if (mxh_partition(box->cfg.n, mxg_ctx_nranks(ctx), mxg_ctx_rank(ctx), pg, box->cfg.boxLo, box->cfg.boxHi) != 0) return 1;
       box->asmb.reset(new mx::YeeAssembler<double>(box->cfg));
-      box->ops = box->asmb->waveOps();
+      // the window chain on this rank's GPU (MXH_DEVICE_CHAIN=0: on the host), as mxh_solver_create does
+      box->ops = box->asmb->singleOps();
+      box->chain_ready = false;
+      {
+        const char* dc = getenv("MXH_DEVICE_CHAIN");
+        if (dc && atoi(dc) == 0) mxh_sim_ensure_chain(box.get());
+        else if (mxh_sim_device_chain(ctx, box.get()) != 0) return 1;
+      }
       box->mask = box->asmb->usedMask();
       s->ownSim = box;
       mxh_solver_build(*s, ctx, box.get(), pl);

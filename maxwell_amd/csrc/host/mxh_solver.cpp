@@ -18,8 +18,12 @@ extern "C" void mxh_solver_default_params(mxh_solver_params* p) {
 void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::ParameterList const& pl) {
   s.comm = rcp(new MxComm(ctx));
   s.params.shift = pl.get("eigensolver : shift", 0.0);
+  // a box of a decomposed grid: the chain of products on its window is formed on this rank's GPU now (a single-rank
+  // sim leaves it to MxMagWaveOp, which never reads the products back)
+  if (sim->asmb->isWindowed() && !sim->chain_ready && mxh_sim_device_chain(ctx, sim) != 0)
+    throw std::runtime_error(mxh_last_error());
   s.sim = rcp(new MxEMSim<3>(sim->cfg, s.comm, pl, sim->asmb));
-  s.sim->setPrebuiltOps(&sim->ops);     // the chain of products was formed when the sim was created
+  s.sim->setPrebuiltOps(&sim->ops);     // single operators, or the whole chain when it has been formed
   s.solver.reset(new MxSolver<3, double>(s.sim, pl));
 }
 

@@ -2,6 +2,8 @@
 maxwell_amd/csrc/device/mxg_spalg.hip) against the chain the host assembler forms (include/mx/mx_sparse.hpp, which
 tests/test_assembly.py pins bit for bit to the oracle): same pattern, same bits, for vacuum / PEC and dielectric
 problems, and the shifted operator of setShift (src/MxMagWaveOp.cpp:248-255)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -19,12 +21,32 @@ def _same(dev, host):
     assert np.array_equal(d.data, h.data)
 
 
+def _same_values(dev, ref):
+    """Against the oracle's scipy operators, which drop the explicit zeros the product keeps (as Epetra does) in the
+    intermediate products: every entry equal on the union pattern."""
+    d = dev.to_scipy(); r = ref.tocsr()
+    d.sort_indices(); r.sort_indices()
+    diff = d - r
+    assert d.shape == r.shape and (diff.nnz == 0 or np.abs(diff.data).max() == 0.0)
+
+
 def _chain(ops, names):
     """massiveCrsMultiply (src/MxUtil.cpp:318-371): the first name is applied first, each step a full product."""
     res = ops[names[0]]
     for nm in names[1:]:
         res = ops[nm].multiply(res)
     return res
+
+
+def _oracle_ops(case):
+    """The same problems in the ORACLE (oracle/yee.py): the device chain is compared with it directly, not only through
+    the product's host chain."""
+    from oracle import geometry as geo, yee
+    if case == "pillbox":
+        return yee.pillbox_sim(16).wave_ops()
+    return yee.YeeSim(12, origin=(0.0,) * 3, size=(0.5,) * 3, lower=("pmc", "pmc", "pec"), upper=("pec",) * 3,
+                      pec=geo.Sphere(0.49, [0, 0, 0]),
+                      dielectrics=[(geo.Sphere(0.37, [0, 0, 0]), 10.0 * np.eye(3), "dielectric0")]).wave_ops()
 
 
 @pytest.mark.parametrize("case", ["pillbox", "dielectric"])
@@ -36,17 +58,23 @@ def test_device_operator_chain_bit_identical_to_host(ctx, case):
         sim = mx.Sim(12, origin=(0, 0, 0), size=(0.5,) * 3, lower=("pmc", "pmc", "pec"), upper=("pec",) * 3,
                      pec_shape="sphere(0.49;0,0,0)", dielectrics=[(10.0, "sphere(0.37;0,0,0)")])
         diel = True
+    oracle = _oracle_ops(case)
     single = ["curlE", "curlB", "divB", "gradPsi", "dmA", "dmL", "dmVInv"] + (["invEps", "invEpsVolAve"] if diel else [])
     ops = {nm: sim.to_device(ctx, nm) for nm in single}
     curlcurl = _chain(ops, ["curlB"] + (["invEps"] if diel else []) + ["dmL", "curlE"])
     _same(curlcurl, sim.op("curlCurl"))
+    _same_values(curlcurl, oracle["curlCurl"])
     graddiv = _chain(ops, ["dmA", "divB", "dmVInv"] + (["invEpsVolAve"] if diel else []) + ["gradPsi", "dmA"])
     _same(graddiv, sim.op("gradDiv"))
+    _same_values(graddiv, oracle["gradDiv"])
     veclapl = curlcurl.add(1.0, graddiv, -1.0).purge(1e-12)
     _same(veclapl, sim.op("vecLapl"))
+    _same(veclapl, oracle["vecLapl"])
     shift = 1.9739208802178716
     shifted = veclapl.add(1.0, ops["dmA"], -shift)          # mRhs = dmA with a PEC (src/MxMagWaveOp.cpp:233-236)
     _same(shifted, sim.op("vecLapl", shift=shift))
+    from oracle import yee as _yee
+    _same_values(shifted, _yee.shifted(oracle["vecLapl"], oracle["mRhs"], shift))
     scalapl = _chain(ops, ["gradPsi", "dmA", "divB"])
     neg = scalapl.add(-1.0, scalapl, 0.0)                   # -(divB dmA gradPsi), :208-220
     host = sim.op("scaLapl")
@@ -94,7 +122,8 @@ def test_device_algebra_general_matrices(ctx, rng):
     E = sp.random(n, m, density=0.01, random_state=5, format="csr"); E.sort_indices()
     S = dA.add(2.0, mx.CsrMatrix.from_scipy(ctx, E), -0.5).to_scipy()
     want = (2.0 * A - 0.5 * E).tocsr(); want.sort_indices()
-    assert np.array_equal(S.indices, (A + E).tocsr().indices if False else S.indices)      # union pattern kept (explicit zeros too)
+    U = (abs(A) + abs(E)).tocsr(); U.sort_indices()                                  # union pattern (no cancellation possible)
+    assert np.array_equal(S.indptr, U.indptr) and np.array_equal(S.indices, U.indices)   # kept entry for entry, explicit zeros too
     assert abs(S - want).max() < 1e-15
     Z = dA.add(1.0, dA, -1.0)                                                         # exact cancellation
     assert Z.nnz == A.nnz and Z.purge().nnz == 0
@@ -124,3 +153,44 @@ def test_eigen_solve_with_the_chain_formed_on_the_device(ctx):
         outs[mode] = json.loads(line[7:])
     assert len(outs["0"]["k2"]) == 4
     assert outs["0"] == outs["1"], outs
+
+
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_device_chain_on_the_window_of_a_decomposed_grid(ctx, nranks):
+    """Row f2 on a decomposed grid (BASELINE config 4): every rank forms the operator chain on its box + halo WINDOW on
+    its GPU (mxh_sim_device_chain, what mxh_solver_create does) - bit-identical to the host chain on the same window,
+    and the owned rows of vecLapl - shift mRhs equal the rows of the ORACLE's global operator entry for entry."""
+    from maxwell_amd import distributed as mxd
+    from maxwell_amd.api import PILLBOX_SHAPE
+    from oracle import geometry as geo, yee
+    n, shift = [12, 10, 14], 1.7
+    box = dict(origin=(-0.5,) * 3, size=(1.0,) * 3)
+    osim = yee.YeeSim(n, pec=geo.pillbox(), **box)
+    o = osim.wave_ops()
+    A = yee.shifted(o["vecLapl"], o["mRhs"], shift).tocsr(); A.sort_indices()
+    gids = osim.B.gids
+    seen = 0
+    for rank in range(nranks):
+        dev = mxd.BoxSim(n, rank, nranks, pec_shape=PILLBOX_SHAPE, **box)
+        dev.form_chain_on_device(ctx)
+        os.environ["MXH_DEVICE_CHAIN"] = "0"
+        try:
+            host = mxd.BoxSim(n, rank, nranks, pec_shape=PILLBOX_SHAPE, **box)
+        finally:
+            os.environ.pop("MXH_DEVICE_CHAIN")
+        for name in ("curlCurl", "gradDiv", "vecLapl", "scaLapl", "mRhs"):
+            d, h = dev.op(name), host.op(name)
+            assert d.shape == h.shape and np.array_equal(d.indptr, h.indptr) and np.array_equal(d.indices, h.indices), (rank, name)
+            assert np.array_equal(d.data, h.data), (rank, name)
+        op = dev.dist_op("shifted", shift)
+        pos = np.searchsorted(gids, op["rowgid"])
+        assert np.array_equal(gids[pos], op["rowgid"])
+        for i, r in enumerate(pos):
+            q0, q1 = op["rowptr"][i], op["rowptr"][i + 1]
+            got = dict(zip(op["colgid"][q0:q1].tolist(), op["vals"][q0:q1].tolist()))
+            want = dict(zip(gids[A.indices[A.indptr[r]:A.indptr[r + 1]]].tolist(), A.data[A.indptr[r]:A.indptr[r + 1]].tolist()))
+            for c in set(got) | set(want):                 # (an explicit zero of the product is no entry of the oracle)
+                assert got.get(c, 0.0) == want.get(c, 0.0), (rank, i, c)
+        seen += len(pos)
+        dev.close(); host.close()
+    assert seen == A.shape[0]
