@@ -40,6 +40,11 @@ class MxCrsMatrix {
   // adopt a finished local CSR (the fast path MxEMOps uses)
   MxCrsMatrix(RCP<MxMap> rowMap, RCP<MxMap> colMap, mx::Csr<Scalar> const& csr)
       : mFilled(false), mRowMap(rowMap), mColMap(colMap), mDev(nullptr) { adopt(csr); }
+  // ... without copying it: the arrays stay the caller's (the operators a sim has assembled outlive the solver built on
+  // them).  The device copy is made from them; a host copy only if something modifies or reads the matrix on the
+  // host.  At 256^3 the single operators are 3.3 GB: copying them was 1 s of the setup and 3 GB of resident memory.
+  MxCrsMatrix(RCP<MxMap> rowMap, RCP<MxMap> colMap, mx::Csr<Scalar> const* borrowed)
+      : mFilled(true), mRowMap(rowMap), mColMap(colMap), mDev(nullptr), mBorrow(borrowed) { mHostValid = false; }
 
   // Row-partitioned operator of a decomposed grid: the owned rows with GLOBAL column ids.  Columns this rank
   // does not own become ghosts and the import plan is agreed with the other ranks here, which is what Epetra's
@@ -61,6 +66,7 @@ class MxCrsMatrix {
       std::cout << "MxCrsMatrix::insertRowValues: row=" << row << " is not on this rank. numEntries=" << numEntries << "\n";
       throw 1;
     }
+    needRows();
     for (size_t i = 0; i < numEntries; ++i) mRows[lr].push_back(std::make_pair(cols[i], vals[i]));
   }
 
@@ -74,6 +80,7 @@ class MxCrsMatrix {
     m.rowptr[0] = 0;
     std::vector<std::pair<int32_t, Scalar> > row;
     std::vector<int32_t> col; std::vector<Scalar> val;
+    needRows();
     for (int64_t r = 0; r < m.nrows; ++r) {
       row.clear();
       for (auto& e : mRows[r]) {
@@ -156,10 +163,11 @@ class MxCrsMatrix {
       MX_ABI(mxg_csr_purge(mRowMap->getComm()->getCtx(), mDev, 1.e-12, &r), "MxCrsMatrix::purgeZeros");
       mxg_csr_destroy(mDev);
       mDev = r;
+      mBorrow = nullptr;                 // the content changed: the borrowed arrays are not this matrix any more
       mCompressed = false;
       return;
     }
-    mx::Csr<Scalar> p = mx::purge(mHost);
+    mx::Csr<Scalar> p = mx::purge(host());
     adopt(p);
   }
 
@@ -220,9 +228,12 @@ class MxCrsMatrix {
   }
 
  private:
-  void initRows() { mRows.resize(mRowMap->getNodeNumIndices()); }
+  // the per-row insertion lists exist only while somebody inserts: a result matrix of the operator chain (formed by
+  // matrixMatrixMultiply / Add, never inserted into) used to allocate and zero 20.6 M empty lists (0.5 GB) at 256^3
+  void initRows() {}
+  void needRows() { if (mRows.size() != (size_t)mRowMap->getNodeNumIndices()) mRows.resize(mRowMap->getNodeNumIndices()); }
   // the device copy is created on first use: setup-only intermediates never reach the GPU
-  void adopt(mx::Csr<Scalar> const& m) { mHost = m; mHostValid = true; upload(); }
+  void adopt(mx::Csr<Scalar> const& m) { mHost = m; mHostValid = true; mBorrow = nullptr; upload(); }
   void upload() {
     if (mDev) { mxg_csr_destroy(mDev); mDev = nullptr; }
     mCompressed = false;
@@ -234,6 +245,7 @@ class MxCrsMatrix {
     mDev = r;
     mHost = mx::Csr<Scalar>();
     mHostValid = false;
+    mBorrow = nullptr;
     mCompressed = false;
     mFilled = true;
     mRows.clear();
@@ -243,6 +255,10 @@ class MxCrsMatrix {
            a.mRowMap->getComm()->numProc() == 1;
   }
   mx::Csr<Scalar> const& host() const {
+    if (!mHostValid && mBorrow) {                 // borrowed arrays: the host copy is made when somebody needs one
+      mHost = *mBorrow;
+      mHostValid = true;
+    }
     if (!mHostValid) {
       int64_t nr = 0, nc = 0, ng = 0, nz = 0;
       int cx = 0;
@@ -262,7 +278,12 @@ class MxCrsMatrix {
     const bool compress = compressEnv && !mNoCompress;
     if (mDev) {
       if (compressIt && compress && !mCompressed && mRowMap->getNodeNumIndices() >= 256) {
-        MX_ABI(mxg_csr_compress(mDev, NULL, NULL, NULL), "MxCrsMatrix (compress)");
+        // a host copy at hand (the multigrid setup has read the matrix back) saves the library its own read-back
+        if (mHostValid)
+          MX_ABI(mxg_csr_compress_from(mDev, mHost.rowptr.data(), mHost.col.data(), reinterpret_cast<const double*>(mHost.val.data()),
+                                       NULL, NULL, NULL), "MxCrsMatrix (compress)");
+        else
+          MX_ABI(mxg_csr_compress(mDev, NULL, NULL, NULL), "MxCrsMatrix (compress)");
         mCompressed = true;
       }
       return;
@@ -274,15 +295,16 @@ class MxCrsMatrix {
     plan.send_idx = mSendIdx.empty() ? &mNoIdx : mSendIdx.data();
     plan.recv_off = mRecvOff.data();
     const bool halo = mDistributed && !mNeigh.empty();
-    MX_ABI(mxg_csr_create(mRowMap->getComm()->getCtx(), mHost.nrows, mHost.ncols - mNumGhost, mNumGhost, mHost.rowptr.data(),
-                          mHost.col.data(), reinterpret_cast<const double*>(mHost.val.data()),
+    const mx::Csr<Scalar>& H = (!mHostValid && mBorrow) ? *mBorrow : mHost;
+    MX_ABI(mxg_csr_create(mRowMap->getComm()->getCtx(), H.nrows, H.ncols - mNumGhost, mNumGhost, H.rowptr.data(),
+                          H.col.data(), reinterpret_cast<const double*>(H.val.data()),
                           ScalarTraits<Scalar>::isComplex, halo ? &plan : NULL, &mDev), "MxCrsMatrix::fillComplete");
     // lattice operators (real or complex) take the tile form - no matrix stream for the bulk rows - other real
     // matrices the compressed stream (mxg_csr_compress; bit-identical results); MXG_COMPRESS=0 keeps the plain CSR
     // kernels.  With ghost columns the tiles and the rows that reference none run while the halo is in flight.
-    if (compressIt && compress && mHost.nrows >= 256) {
-      MX_ABI(mxg_csr_compress_from(mDev, mHost.rowptr.data(), mHost.col.data(),
-                                   reinterpret_cast<const double*>(mHost.val.data()), NULL, NULL, NULL),
+    if (compressIt && compress && H.nrows >= 256) {
+      MX_ABI(mxg_csr_compress_from(mDev, H.rowptr.data(), H.col.data(),
+                                   reinterpret_cast<const double*>(H.val.data()), NULL, NULL, NULL),
              "MxCrsMatrix::fillComplete (compress)");
       mCompressed = true;
     }
@@ -441,6 +463,7 @@ class MxCrsMatrix {
   RCP<MxMap> mRowMap, mColMap;
   std::vector<std::vector<std::pair<MxIndex, Scalar> > > mRows;
   mutable mx::Csr<Scalar> mHost;     // (filled on demand for a matrix formed on the device: host())
+  mx::Csr<Scalar> const* mBorrow = nullptr;   // the caller's arrays of a borrowed matrix (valid until the matrix is modified)
   mutable bool mHostValid = true;
   mutable bool mCompressed = false, mNoCompress = false;
   mutable std::atomic<int> mApplies{0};    // applies so far (a matrix may be applied from several rank threads)

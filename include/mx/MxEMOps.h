@@ -93,7 +93,7 @@ class MxEMOps {
     else if (name == "gradPsi") { cols = p; }
     else if (name == "dmL" || name == "invEps") { rows = e; cols = e; }
     else if (name == "dmVInv" || name == "invEpsVolAve" || name == "invMuVolAve" || name == "scaLapl") { rows = p; cols = p; }
-    if (!mSim->isDistributed()) { mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, m)); return; }
+    if (!mSim->isDistributed()) { mOps[name] = rcp(new MxCrsMatrix<Scalar>(rows, cols, &m)); return; }   // borrowed: no copy
     mOps[name] = distributed(rows, cols, fieldOf(rows, b, e), fieldOf(cols, b, e), m);
   }
   // the owned rows of a window-level operator (box + halo numbering) as a row-partitioned matrix; COLLECTIVE
