@@ -35,6 +35,8 @@ for rnd in range(2):
     for name, parts, order in (("tiles", 1, 0), ("groups", 4, 0), ("all_first", 15, 0), ("all_last", 15, 1), ("all_spread", 15, 2)):
         rc = exp.exp_tile_time(ctx.h, A.h, X.h, Y.h, parts, order, 50, C.byref(ms))
         out.setdefault(name, []).append(round(ms.value, 5) if rc == 0 else "rc %d" % rc)
+rc = exp.exp_tile_two_streams(ctx.h, A.h, X.h, Y.h, 50, C.byref(ms))
+out["two_streams"] = round(ms.value, 5) if rc == 0 else "rc %d" % rc
 X8 = mx.MultiVec(ctx, A.ncols, 8); Y8 = mx.MultiVec(ctx, A.nrows, 8); X8.random(1)
 for name, parts, order in (("k8_first", 15, 0), ("k8_spread", 15, 2)):
     rc = exp.exp_tile_time(ctx.h, A.h, X8.h, Y8.h, parts, order, 10, C.byref(ms))

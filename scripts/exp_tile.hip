@@ -37,6 +37,47 @@ extern "C" int exp_tile_time(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y,
   return 0;
 }
 
+// tiles on the compute stream, group rows on the communication stream, concurrently (two launches): ms per pair
+extern "C" int exp_tile_two_streams(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int reps, float* ms) {
+  if (!a->tile_on || a->is_complex) return 1;
+  auto args = [&](int parts) {
+    TileArgs A{};
+    A.ntA = (parts & 1) ? a->tile_ntA : 0;
+    A.grow = a->d_grow; A.gcol = a->d_gcol; A.gval = a->d_gval; A.lrows = a->d_lrows;
+    A.rowptr = (const long long*)a->d_rowptr; A.colidx = a->d_colidx; A.vals = a->d_vals;
+    A.ldx = x->ld; A.ldy = y->ld; A.order = 0; A.nowned = a->ncols_owned;
+    A.ng0 = 0; A.ngn = (parts & 4) ? a->gen_ngrp : 0; A.nl0 = 0; A.nln = 0;
+    A.ngbG = ceil_div(A.ngn, TILE_WAVES); A.ngbL = 0; A.ngb = up8(A.ngbG);
+    A.ntbA = ceil_div(A.ntA, (long long)TILE_WAVES * TILE_TPW); A.ntbB = 0;
+    return A;
+  };
+  const TileArgs T = args(1), G = args(4);
+  const long long gt = T.ngb + up8(T.ntbA), gg = G.ngb + up8(G.ntbA);
+  hipEvent_t e2;
+  hipEventCreate(&e2);
+  auto pair = [&]() {
+    hipEventRecord(c->ev_pack, c->stream);
+    hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0);
+    hipLaunchKernelGGL((k_spmv_tile<false, false, 0, false>), dim3((unsigned)gg), dim3(TILE_BLOCK), 0, c->comm_stream,
+                       (const TileDesc*)a->d_tiledescA, (const void*)a->d_tiledictA, (const GenGroup*)a->d_ggrp,
+                       (const double*)x->colptr(0), y->colptr(0), G);
+    hipLaunchKernelGGL((k_spmv_tile<false, false, 0, false>), dim3((unsigned)gt), dim3(TILE_BLOCK), 0, c->stream,
+                       (const TileDesc*)a->d_tiledescA, (const void*)a->d_tiledictA, (const GenGroup*)a->d_ggrp,
+                       (const double*)x->colptr(0), y->colptr(0), T);
+    hipEventRecord(e2, c->comm_stream);
+    hipStreamWaitEvent(c->stream, e2, 0);
+  };
+  for (int r = 0; r < 3; ++r) pair();
+  hipEventRecord(c->ev0, c->stream);
+  for (int r = 0; r < reps; ++r) pair();
+  hipEventRecord(c->ev1, c->stream);
+  if (hipEventSynchronize(c->ev1) != hipSuccess) return 2;
+  hipEventElapsedTime(ms, c->ev0, c->ev1);
+  *ms /= reps;
+  hipEventDestroy(e2);
+  return 0;
+}
+
 // ---- pure stream variants: read n16 16-byte pieces, write m16 ------------------------------------------------------
 typedef double d2 __attribute__((ext_vector_type(2)));
 template <bool NT, int U, bool CHUNK>
