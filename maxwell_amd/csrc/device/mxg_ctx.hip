@@ -60,6 +60,7 @@ extern "C" int mxg_ctx_create(int device, int rank, int nranks, const void* nccl
   MXG_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   MXG_HIP(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
   MXG_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  MXG_HIP(hipEventCreateWithFlags(&c->ev_scal, hipEventDisableTiming));
   MXG_HIP(hipEventCreate(&c->ev0));
   MXG_HIP(hipEventCreate(&c->ev1));
   MXG_CHECK(nranks == 1 || nccl_unique_id != nullptr, "mxg_ctx_create: nranks > 1 needs an RCCL unique id");
@@ -89,6 +90,7 @@ extern "C" int mxg_ctx_destroy(mxg_ctx* c) {
   hipEventDestroy(c->ev1);
   if (c->ev_pack) hipEventDestroy(c->ev_pack);
   if (c->ev_halo) hipEventDestroy(c->ev_halo);
+  if (c->ev_scal) hipEventDestroy(c->ev_scal);
   if (c->comm_stream) { hipStreamSynchronize(c->comm_stream); hipStreamDestroy(c->comm_stream); }
   hipStreamDestroy(c->stream);
   delete c;

@@ -65,6 +65,7 @@ struct mxg_ctx {
   // halo exchange runs on its own stream so that interior rows overlap it (ev_pack / ev_halo order the two)
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+  hipEvent_t ev_scal = nullptr;           // "the scalars of this iteration are on the host" (multigrid-CG convergence test)
   // reduction workspace: partial sums + results (device), results (pinned host)
   double* d_partial = nullptr;   // MXG_MAX_RED_BLOCKS * red_width doubles
   double* d_result = nullptr;    // red_width doubles

@@ -626,19 +626,32 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
                            mgprec ? (double*)nullptr : z->colptr(0), diag, (const double*)scal, cur, c->d_partial);
         hipLaunchKernelGGL(k_cg_reduce2, dim3(2), dim3(CGB), 0, c->stream, (const double*)c->d_partial, grid,
                            scal, nxt);
-        if (mgprec) {            // z = V-cycle(r), r.z replaces the placeholder the update kernel left in slot nxt
+        if (mgprec) {
+          // r.r and p.q are final here: send them to the host now and enqueue the V-cycle behind the copy, so that the
+          // convergence test below waits for an event the GPU passed a cycle ago and the next iteration is enqueued
+          // while this cycle still runs (a stream synchronisation per iteration left the GPU idle ~90 us each)
+          if (mxg_comm_on(c)) MXG_TRY(allreduce(scal + S_RR, 1));
+          MXG_HIP(hipMemcpyAsync(c->h_result, scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+          MXG_HIP(hipEventRecord(c->ev_scal, c->stream));
+          // z = V-cycle(r), r.z replaces the placeholder the update kernel left in slot nxt
           MXG_TRY(mgprecond());
           MXG_TRY(mxg_dev_dot(c, r->desc(), zc->desc(), scal + nxt));
+          if (mxg_comm_on(c)) MXG_TRY(allreduce(scal + nxt, 1));
+        } else if (mxg_comm_on(c)) {
+          MXG_TRY(allreduce(scal + std::min(nxt, (int)S_RR), 2));   // r.z (slot nxt) and r.r, adjacent
         }
-        if (mxg_comm_on(c)) MXG_TRY(allreduce(scal + std::min(nxt, (int)S_RR), 2));   // r.z (slot nxt) and r.r, adjacent
         hipLaunchKernelGGL(k_cg_dir, dim3(grid), dim3(CGB), 0, c->stream, n, p->colptr(0),
                            (const double*)zc->colptr(0), (const double*)scal, cur, nxt);
         cur = nxt;
       }
       MXG_HIP(hipGetLastError());
       it += todo;
-      MXG_HIP(hipMemcpyAsync(c->h_result, scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
-      MXG_HIP(hipStreamSynchronize(c->stream));
+      if (mgprec) {
+        MXG_HIP(hipEventSynchronize(c->ev_scal));
+      } else {
+        MXG_HIP(hipMemcpyAsync(c->h_result, scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+        MXG_HIP(hipStreamSynchronize(c->stream));
+      }
       const double rr = c->h_result[S_RR];
       if (!(rr == rr) || c->h_result[S_PQ] == 0.0) { stalled = true; break; }   // NaN or breakdown
       rnorm = sqrt(rr);

@@ -8,5 +8,7 @@ MXH_VERBOSE=1 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format
 rc=$?; echo "rc=$rc"; tail -3 $OUT/prof_eigen_$TAG.log
 f=$(find $OUT/prof_eigen_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f $OUT/eigen_kernel_stats_$TAG.csv && head -30 $f
-# the kernel trace itself is large: keep only the statistics
+# busy / idle time of the GPU inside the inner solves, then drop the trace (large): keep only the statistics
+t=$(find $OUT/prof_eigen_$TAG -name "*kernel_trace.csv" | head -1)
+[ -n "$t" ] && python $ROOT/scripts/trace_busy.py $t > $OUT/eigen_busy_$TAG.json && cat $OUT/eigen_busy_$TAG.json
 find $OUT/prof_eigen_$TAG -name "*kernel_trace.csv" -delete
