@@ -1691,6 +1691,34 @@ int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, in
   return 0;
 }
 
+// A smoother step (epilogue 1 or 4) whose launch also leaves d_out[0] = y_new . rhs (owned rows): the multigrid-CG takes
+// its r.z from the last step of the cycle instead of a pass of its own over r and z.  Tile form only: returns 1
+// (nothing launched) for any other form, 0 when done, 2 on an error.
+int mxg_dev_csr_apply_epi_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
+                              const double* diag, double omega, double beta, double* d_out) {
+  if (!(tile_active(a) && !a->is_complex && x->k == 1 && y->k == 1 && x->base != y->base && (epi == 1 || epi == 4))) return 1;
+  const bool halo = is_halo(a);
+  const int64_t np = mxg_tile_partials(a);
+  if (np <= 0) return 1;
+  if (!a->d_dotpartial || a->dotpartial_cap < np) {
+    if (a->d_dotpartial) hipFree(a->d_dotpartial);
+    if (hipMalloc(&a->d_dotpartial, sizeof(double) * np) != hipSuccess) { mxg_set_error("mxg_dev_csr_apply_epi_dot: out of memory"); return 2; }
+    a->dotpartial_cap = np;
+  }
+  if (halo) {
+    if (halo_start(c, a, x) != 0) return 2;
+    if (a->nrows == 0) {
+      hipStreamWaitEvent(c->stream, c->ev_halo, 0);
+      return hipMemsetAsync(d_out, 0, sizeof(double), c->stream) == hipSuccess ? 0 : 2;
+    }
+  }
+  (void)hipGetLastError();
+  if (mxg_tile_launch(c, a, x->colptr(0), x->ld, y->colptr(0), y->ld, 1, epi, 1, nullptr, a->d_dotpartial, rhs, diag, omega, beta,
+                      halo ? 1 : 0, a->d_ghost, a->ldghost)) return 2;
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, (const double*)a->d_dotpartial, (long long)np, d_out);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 // y = A x and d_out[0] = x . y in one pass over the matrix (real, one column, row-gather geometry).
 // x . y uses the owned rows only; the caller all-reduces d_out across ranks if needed.
 int mxg_dev_csr_apply_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out) {

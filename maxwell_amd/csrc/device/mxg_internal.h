@@ -218,6 +218,8 @@ int mxg_dev_csr_apply_ell(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y);
 // 0: launched; 1: matrix not compressed / shape not supported (nothing done); 2: launch error
 int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
                           const double* diag, double omega, double beta = 0.0);
+int mxg_dev_csr_apply_epi_dot(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
+                              const double* diag, double omega, double beta, double* d_out);
 int mxg_dev_csr_apply_dot(mxg_ctx* ctx, mxg_csr* a, const mxg_mv* x, mxg_mv* y, double* d_out);
 
 // tile product (mxg_tile.hip)

@@ -70,7 +70,8 @@ enum { S_RZ0 = 0, S_RR = 1, S_RZ1 = 2, S_PQ = 3 };   // r.r sits between the two
 __global__ void k_cg_update(long long n, double* __restrict__ x, double* __restrict__ r,
                             const double* __restrict__ p, const double* __restrict__ q,
                             double* __restrict__ z, const double* __restrict__ diag,
-                            const double* __restrict__ scal, int irz, double* __restrict__ partial) {
+                            const double* __restrict__ scal, int irz, double* __restrict__ partial,
+                            double* __restrict__ zmg, const double* __restrict__ dmg, double omg) {
   __shared__ double lds[2][CGB / 64];
   const double pq = scal[S_PQ];
   const double alpha = pq != 0.0 ? scal[irz] / pq : 0.0;
@@ -82,7 +83,8 @@ __global__ void k_cg_update(long long n, double* __restrict__ x, double* __restr
     r[i] = ri;
     double zi = ri;
     if (diag) { const double d = diag[i]; zi = d != 0.0 ? ri / d : 0.0; }
-    if (z) z[i] = zi;          // z == nullptr: the preconditioner (multigrid) forms z afterwards
+    if (z) z[i] = zi;          // z == nullptr: the preconditioner (multigrid) forms z afterwards ...
+    if (zmg) { const double d = dmg[i]; zmg[i] = d != 0.0 ? omg * ri / d : 0.0; }   // ... from this first smoother step (k_jac_first's arithmetic)
     srz += ri * zi;
     srr += ri * ri;
   }
@@ -146,6 +148,9 @@ struct mxg_mg {
   double coarse_cheb_ratio = 100.0;
   std::vector<double> lmax;
   std::vector<mxg_mv*> u;             // product scratch of the unfused Chebyshev step
+  double* dot_out = nullptr;          // multigrid-CG: where the cycle's last level-0 smoother step leaves z . r (device) ...
+  bool dot_done = false;              // ... and whether it did (tile form only; the caller runs a dot kernel otherwise)
+  bool first_done = false;            // multigrid-CG: the level-0 vector z already holds the first smoother step (k_cg_update wrote it)
   mxg_mg* tail = nullptr;
   std::vector<int64_t> tail_counts;
   int64_t tail_pad = 0, tail_off = 0;
@@ -263,7 +268,7 @@ int small_max_row_len(mxg_ctx* c, mxg_csr* A, int* out) {
 }
 
 // `sweeps` steps of the Chebyshev iteration for D^-1 A on [lmax / ratio, lmax] (Saad, Iterative Methods, Alg. 12.1)
-int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio) {
+int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio, bool want_dot = false) {
   mxg_ctx* c = mg->ctx;
   mxg_csr* A = mg->A[l];
   const long long n = A->nrows;
@@ -271,6 +276,8 @@ int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio)
   const double lmax = mg->lmax[l], lmin = lmax / ratio;
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma1 = theta / delta;
   double rho = 1.0 / sigma1;
+  const bool skip_first = l == 0 && zero_guess && mg->first_done;
+  if (l == 0) mg->first_done = false;
   static const bool small_kernel = !(getenv("MXG_MG_SMALL_KERNEL") && atoi(getenv("MXG_MG_SMALL_KERNEL")) == 0);
   int maxlen = CHEB_SMALL_LEN + 1;
   if (small_kernel && zero_guess && sweeps >= 2 && sweeps <= CHEB_SMALL_STEPS && n <= CHEB_SMALL_ROWS && n > 0 && !A->is_complex &&
@@ -294,6 +301,7 @@ int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio)
     double omega, beta;
     if (s == 0) { omega = 1.0 / theta; beta = 0.0; }
     else { const double rn = 1.0 / (2.0 * sigma1 - rho); omega = 2.0 * rn / delta; beta = rn * rho; rho = rn; }
+    if (s == 0 && zero_guess && skip_first) { prev_zero = true; continue; }
     if (s == 0 && zero_guess) {
       hipLaunchKernelGGL(k_jac_first, dim3(grid), dim3(256), 0, c->stream, n, (const double*)A->d_diag, omega,
                          (const double*)mg->r[l]->colptr(0), mg->z[l]->colptr(0));
@@ -302,7 +310,12 @@ int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio)
     }
     // the previous iterate sits in t and is overwritten by the new one
     const int epi = s == 0 ? 1 : (prev_zero ? 5 : 4);
-    const int rc = mxg_dev_csr_apply_epi(c, A, mg->z[l], mg->t[l], epi, mg->r[l]->colptr(0), A->d_diag, omega, beta);
+    int rc = 1;
+    if (want_dot && s == sweeps - 1 && mg->dot_out && epi != 5) {      // last step of the cycle: z . r rides along
+      rc = mxg_dev_csr_apply_epi_dot(c, A, mg->z[l], mg->t[l], epi, mg->r[l]->colptr(0), A->d_diag, omega, beta, mg->dot_out);
+      if (rc == 0) mg->dot_done = true;
+    }
+    if (rc == 1) rc = mxg_dev_csr_apply_epi(c, A, mg->z[l], mg->t[l], epi, mg->r[l]->colptr(0), A->d_diag, omega, beta);
     if (rc > 1) return 1;
     if (rc == 1) {
       MXG_TRY(mxg_csr_apply(c, A, mg->z[l], mg->u[l]));
@@ -317,12 +330,12 @@ int mg_smooth_cheb(mxg_mg* mg, int l, int sweeps, bool zero_guess, double ratio)
   return 0;
 }
 
-int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess) {
+int mg_smooth(mxg_mg* mg, int l, int sweeps, bool zero_guess, bool want_dot = false) {
   mxg_ctx* c = mg->ctx;
   mxg_csr* A = mg->A[l];
   const long long n = A->nrows;
   const int grid = mxg_grid_for(n, 256, 2, 8 * c->num_cu);
-  if (mg->cheb && l < mg->nlevels - 1) return mg_smooth_cheb(mg, l, sweeps, zero_guess, mg->cheb_ratio);
+  if (mg->cheb && l < mg->nlevels - 1) return mg_smooth_cheb(mg, l, sweeps, zero_guess, mg->cheb_ratio, want_dot);
   if (mg->cheb && mg->coarse_cheb_degree > 0) return mg_smooth_cheb(mg, l, mg->coarse_cheb_degree, zero_guess, mg->coarse_cheb_ratio);
   for (int s = 0; s < sweeps; ++s) {
     if (s == 0 && zero_guess) {
@@ -396,7 +409,7 @@ int mg_cycle(mxg_mg* mg, int l) {
                        (const double*)mg->t[l]->colptr(0), mg->z[l]->colptr(0));
   }
   MXG_HIP(hipGetLastError());
-  return mg_smooth(mg, l, sw, false);
+  return mg_smooth(mg, l, sw, false, l == 0);
 }
 
 }  // namespace
@@ -562,15 +575,33 @@ namespace {
 
 // One V-cycle with the caller's r as the level-0 right-hand side; the result stays in the hierarchy's own level-0
 // vector (*z_out, valid until the next cycle): the multigrid-CG loop saves two vector copies per iteration.
-int mg_apply_nocopy(mxg_ctx* c, mxg_mg* mg, mxg_mv* r, mxg_mv** z_out) {
+// d_rz (optional): r . z (owned rows, not all-reduced) goes there - from the cycle's last smoother step when the level-0
+// operator has the tile form, from a dot kernel otherwise.
+int mg_apply_nocopy(mxg_ctx* c, mxg_mg* mg, mxg_mv* r, mxg_mv** z_out, double* d_rz = nullptr) {
   MXG_CHECK(r->k == 1 && !r->is_complex && r->nlocal == mg->A[0]->nrows, "multigrid: shape mismatch");
-  (void)c;
   mxg_mv* own = mg->r[0];
   mg->r[0] = r;
+  static const bool fuse = !(getenv("MXG_MG_FUSED_DOT") && atoi(getenv("MXG_MG_FUSED_DOT")) == 0);   // experiments
+  mg->dot_out = fuse ? d_rz : nullptr; mg->dot_done = false;
   const int rc = mg_cycle(mg, 0);
   mg->r[0] = own;
+  mg->dot_out = nullptr;
   *z_out = mg->z[0];
+  if (rc == 0 && d_rz && !mg->dot_done) return mxg_dev_dot(c, r->desc(), mg->z[0]->desc(), d_rz);
   return rc;
+}
+
+// The first smoother step of the next cycle, for the caller to fold into its own pass over the residual: z_0 = omega D^-1 r
+// into *z (the hierarchy's level-0 vector).  Returns false when the cycle does not start that way; after writing z the
+// caller sets mg->first_done.
+bool mg_first_step(mxg_mg* mg, double** z, const double** diag, double* omega) {
+  static const bool fuse = !(getenv("MXG_MG_FUSED_FIRST") && atoi(getenv("MXG_MG_FUSED_FIRST")) == 0);   // experiments
+  if (!fuse || !mg->cheb || mg->nlevels < 2 || mg->pre < 1 || mg->A[0]->nrows <= CHEB_SMALL_ROWS || !mg->A[0]->d_diag) return false;
+  const double lmax = mg->lmax[0], lmin = lmax / mg->cheb_ratio;
+  *omega = 1.0 / (0.5 * (lmax + lmin));
+  *z = mg->z[0]->colptr(0);
+  *diag = (const double*)mg->A[0]->d_diag;
+  return true;
 }
 
 // z = M^-1 v where the caller only reads the result before the next application: with the multigrid (real
@@ -605,12 +636,13 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
   MXG_TRY(true_residual(c, A, b, x, r, &res));
   int it = 0;
   mxg_mv* zc = z;                        // where the preconditioned residual sits (multigrid: its own level-0 vector)
-  auto mgprecond = [&]() -> int { return mg_apply_nocopy(c, o->mg, r, &zc); };   // A/B at 256^3: -4.6 % vs two copies
+  // z = V-cycle(r) (in the hierarchy's own vector: -4.6 % at 256^3 against two copies) and r.z into slot `slot`
+  auto mgprecond = [&](int slot) -> int { return mg_apply_nocopy(c, o->mg, r, &zc, scal + slot); };
   while (res > o->tol && it < max_iters) {
-    if (mgprec) MXG_TRY(mgprecond());
+    if (mgprec) MXG_TRY(mgprecond(S_RZ0));
     else MXG_TRY(apply_prec(c, A, o, r, z));
     MXG_TRY(mxg_mv_copy(p, zc));
-    MXG_TRY(mxg_dev_dot(c, r->desc(), zc->desc(), scal + S_RZ0));
+    if (!mgprec) MXG_TRY(mxg_dev_dot(c, r->desc(), zc->desc(), scal + S_RZ0));
     MXG_TRY(allreduce(scal + S_RZ0, 1));
     int cur = S_RZ0;
     double rnorm = res;
@@ -621,9 +653,13 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
         const int nxt = cur == S_RZ0 ? S_RZ1 : S_RZ0;
         MXG_TRY(mxg_dev_csr_apply_dot(c, A, p, q, scal + S_PQ));
         MXG_TRY(allreduce(scal + S_PQ, 1));
+        double* zmg = nullptr; const double* dmg = nullptr; double omg = 0.0;
+        const bool first = mgprec && mg_first_step(o->mg, &zmg, &dmg, &omg);
         hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(CGB), 0, c->stream, n, x->colptr(0), r->colptr(0),
                            (const double*)p->colptr(0), (const double*)q->colptr(0),
-                           mgprec ? (double*)nullptr : z->colptr(0), diag, (const double*)scal, cur, c->d_partial);
+                           mgprec ? (double*)nullptr : z->colptr(0), diag, (const double*)scal, cur, c->d_partial,
+                           first ? zmg : (double*)nullptr, dmg, omg);
+        if (first) o->mg->first_done = true;
         hipLaunchKernelGGL(k_cg_reduce2, dim3(2), dim3(CGB), 0, c->stream, (const double*)c->d_partial, grid,
                            scal, nxt);
         if (mgprec) {
@@ -634,8 +670,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
           MXG_HIP(hipMemcpyAsync(c->h_result, scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
           MXG_HIP(hipEventRecord(c->ev_scal, c->stream));
           // z = V-cycle(r), r.z replaces the placeholder the update kernel left in slot nxt
-          MXG_TRY(mgprecond());
-          MXG_TRY(mxg_dev_dot(c, r->desc(), zc->desc(), scal + nxt));
+          MXG_TRY(mgprecond(nxt));
           if (mxg_comm_on(c)) MXG_TRY(allreduce(scal + nxt, 1));
         } else if (mxg_comm_on(c)) {
           MXG_TRY(allreduce(scal + std::min(nxt, (int)S_RR), 2));   // r.z (slot nxt) and r.r, adjacent

@@ -171,11 +171,11 @@ __device__ inline void tile_rows_real(const TileDesc* __restrict__ desc, const E
           sum.x = sum.x + va * xv[u][i].x;
           sum.y = sum.y + vb * xv[u][i].y;
         }
-      dbl2p o;
+      dbl2p o, rr;
       if (EPI == 0) {
         o = sum;
       } else {
-        dbl2p rr, dg, xr, yy;
+        dbl2p dg, xr, yy;
         if (EPI != 3) { const dbl2u q = *reinterpret_cast<const dbl2u*>(A.rhs + row); rr.x = q.x; rr.y = q.y; }
         if (EPI == 1 || EPI == 4 || EPI == 5) {
           const dbl2u q2 = *reinterpret_cast<const dbl2u*>(x + row);
@@ -209,7 +209,10 @@ __device__ inline void tile_rows_real(const TileDesc* __restrict__ desc, const E
       // about to gather - measured 0.105 against 0.054 ms on the tile rows (scripts/ubench_gather.hip, v6)
       dbl2u ou; ou.x = o.x; ou.y = o.y;
       __builtin_nontemporal_store(ou, reinterpret_cast<dbl2u*>(y + row));
-      if (DOT) { const dbl2u xd = *reinterpret_cast<const dbl2u*>(A.xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+      if (DOT) {
+        if (EPI == 0) { const dbl2u xd = *reinterpret_cast<const dbl2u*>(A.xdot + row); part += sum.x * xd.x; part += sum.y * xd.y; }
+        else { part += o.x * rr.x; part += o.y * rr.y; }           // smoother step: (new iterate) . rhs
+      }
     }
 }
 
@@ -317,8 +320,9 @@ __device__ inline void group_rows(long long wg, const GenGroup* __restrict__ ggr
       dbl2p o; o.x = sr; o.y = si;
       __builtin_nontemporal_store(o, reinterpret_cast<dbl2p*>(y) + row);
     } else {
-      __builtin_nontemporal_store(tile_epilogue<EPI>(sr, row, x, A.rhs, A.diag, A.omega, A.beta, y), y + row);
-      if (DOT) part += sr * A.xdot[row];
+      const double out = tile_epilogue<EPI>(sr, row, x, A.rhs, A.diag, A.omega, A.beta, y);
+      __builtin_nontemporal_store(out, y + row);
+      if (DOT) part += EPI == 0 ? sr * A.xdot[row] : out * A.rhs[row];
     }
   }
 }
@@ -348,8 +352,9 @@ __device__ inline void long_rows(long long wg, const double* __restrict__ x, dou
   }
   if (CPLX) { y[2 * row] = sr; y[2 * row + 1] = si; }
   else {
-    y[row] = tile_epilogue<EPI>(sr, row, x, A.rhs, A.diag, A.omega, A.beta, y);
-    if (DOT) part += sr * A.xdot[row];
+    const double out = tile_epilogue<EPI>(sr, row, x, A.rhs, A.diag, A.omega, A.beta, y);
+    y[row] = out;
+    if (DOT) part += EPI == 0 ? sr * A.xdot[row] : out * A.rhs[row];
   }
 }
 
@@ -685,13 +690,15 @@ int64_t mxg_tile_partials(const mxg_csr* a) {
 // y = epilogue(A x) for k columns (x, y: first column and leading dimension in doubles).  halo: the matrix has ghost
 // columns and the caller has started the exchange (halo_start): tiles and ghost-free groups are launched at once, the
 // stream then waits for the halo event and the ghost-reading groups follow, reading xg (column j at xg + j * ldg).
-// dot: per-workgroup partial sums of (A x) . xdot go to partial[0 .. mxg_tile_partials).  epi / dot: k = 1, real.
+// dot: per-workgroup partial sums of (A x) . xdot go to partial[0 .. mxg_tile_partials); with epilogue 1 / 4 (a smoother
+// step) the sums are (new iterate) . rhs instead - the r.z of the multigrid-CG from the cycle's last step.  epi / dot: k = 1, real.
 int mxg_tile_launch(mxg_ctx* c, mxg_csr* a, const double* x, long long ldx, double* y, long long ldy, int k, int epi,
                     int dot, const double* xdot, double* partial, const double* rhs, const double* diag, double omega,
                     double beta, int halo, const double* xg, long long ldg) {
   MXG_CHECK(a->tile_on, "mxg_tile_launch: the matrix has no tile form");
   MXG_CHECK(!(a->is_complex && (epi != 0 || dot)), "mxg_tile_launch: complex products have no fused epilogue");
   MXG_CHECK(k == 1 || (epi == 0 && !dot), "mxg_tile_launch: fused epilogues take one column");
+  MXG_CHECK(!dot || epi == 0 || epi == 1 || epi == 4, "mxg_tile_launch: the fused dot goes with the plain product or a smoother step (epilogue 1 / 4)");
   TileArgs A{};
   A.ntA = a->tile_ntA; A.ntB = a->tile_ntB;
   A.grow = a->d_grow; A.gcol = a->d_gcol; A.gval = a->d_gval;
@@ -705,6 +712,8 @@ int mxg_tile_launch(mxg_ctx* c, mxg_csr* a, const double* x, long long ldx, doub
     if (g.ntbA == 0) A.ntA = 0;
     if (g.ntbB == 0) A.ntB = 0;
     if (a->is_complex) launch_phase<true, false, 0>(c, a, x, y, k, A, g, h);
+    else if (dot && epi == 4) launch_phase<false, true, 4>(c, a, x, y, k, A, g, h);
+    else if (dot && epi == 1) launch_phase<false, true, 1>(c, a, x, y, k, A, g, h);
     else if (dot) launch_phase<false, true, 0>(c, a, x, y, k, A, g, h);
     else if (epi == 1) launch_phase<false, false, 1>(c, a, x, y, k, A, g, h);
     else if (epi == 2) launch_phase<false, false, 2>(c, a, x, y, k, A, g, h);
