@@ -75,11 +75,62 @@ extern "C" int mxg_ctx_create(int device, int rank, int nranks, const void* nccl
   return 0;
 }
 
+// ---- vector storage cache ------------------------------------------------------------------------------------------
+// Reuse is ordered by ctx->stream: a released buffer may still be read by kernels already enqueued there, and the next
+// owner's first use is enqueued behind them.  (Vectors are only ever touched on ctx->stream, or on ctx->comm_stream
+// between events that ctx->stream waits for.)
+namespace {
+constexpr size_t VEC_CACHE_MAX_BYTES = (size_t)8 << 30, VEC_CACHE_MAX_ONE = (size_t)2 << 30, VEC_CACHE_MAX_COUNT = 32;
+}
+
+int mxg_vec_alloc(mxg_ctx* c, size_t bytes, void** out) {
+  {
+  std::lock_guard<std::mutex> lock(c->vec_cache_mutex);
+  for (size_t i = c->vec_cache.size(); i-- > 0;)
+    if (c->vec_cache[i].first == bytes) {
+      *out = c->vec_cache[i].second;
+      c->vec_cache_bytes -= bytes;
+      c->vec_cache.erase(c->vec_cache.begin() + (long)i);
+      return 0;
+    }
+  }
+  if (hipMalloc(out, bytes) == hipSuccess) return 0;
+  (void)hipGetLastError();
+  mxg_vec_cache_flush(c);                     // out of memory: give the cached buffers back and try once more
+  MXG_HIP(hipMalloc(out, bytes));
+  return 0;
+}
+
+void mxg_vec_release(mxg_ctx* c, void* p, size_t bytes) {
+  static const bool off = getenv("MXG_VEC_CACHE") && atoi(getenv("MXG_VEC_CACHE")) == 0;   // experiments
+  {
+    std::lock_guard<std::mutex> lock(c->vec_cache_mutex);
+    if (!off && bytes <= VEC_CACHE_MAX_ONE && c->vec_cache.size() < VEC_CACHE_MAX_COUNT &&
+        c->vec_cache_bytes + bytes <= VEC_CACHE_MAX_BYTES) {
+      c->vec_cache.emplace_back(bytes, p);
+      c->vec_cache_bytes += bytes;
+      return;
+    }
+  }
+  hipStreamSynchronize(c->stream);
+  hipFree(p);
+}
+
+void mxg_vec_cache_flush(mxg_ctx* c) {
+  std::lock_guard<std::mutex> lock(c->vec_cache_mutex);
+  if (c->vec_cache.empty()) return;
+  hipStreamSynchronize(c->stream);
+  for (auto& e : c->vec_cache) hipFree(e.second);
+  c->vec_cache.clear();
+  c->vec_cache_bytes = 0;
+}
+
 extern "C" int mxg_ctx_destroy(mxg_ctx* c) {
   if (!c || !mxg_ctx_alive(c)) return 0;
   { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_live_ctx.erase(c); }
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  mxg_vec_cache_flush(c);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->d_partial) hipFree(c->d_partial);
   if (c->d_result) hipFree(c->d_result);

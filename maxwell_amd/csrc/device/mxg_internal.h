@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "mxg.h"
@@ -66,6 +68,11 @@ struct mxg_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
   hipEvent_t ev_scal = nullptr;           // "the scalars of this iteration are on the host" (multigrid-CG convergence test)
+  // released vector storage, kept for the next vector of the same size (mxg_vec_alloc / mxg_vec_release): the work
+  // vectors of an inner solve and the clones of the eigensolver come and go per call, and hipFree stalls the device
+  std::vector<std::pair<size_t, void*> > vec_cache;
+  size_t vec_cache_bytes = 0;
+  std::mutex vec_cache_mutex;             // a binding's finaliser may release a vector from another thread
   // reduction workspace: partial sums + results (device), results (pinned host)
   double* d_partial = nullptr;   // MXG_MAX_RED_BLOCKS * red_width doubles
   double* d_result = nullptr;    // red_width doubles
@@ -209,6 +216,10 @@ int mxg_ctx_finish_reduce(mxg_ctx* ctx, size_t width, double* host_out);
 // device-side entry points used across translation units (results stay on device)
 // d_out[j] = sum_i conj(A_j[i]) * B_j[i]; complex results interleaved. No all-reduce, no sync.
 int mxg_dev_dot(mxg_ctx* ctx, const MvDesc& A, const MvDesc& B, double* d_out);
+// vector storage through the context's cache (stream-ordered reuse on ctx->stream; contents undefined)
+int mxg_vec_alloc(mxg_ctx* c, size_t bytes, void** out);
+void mxg_vec_release(mxg_ctx* c, void* p, size_t bytes);
+void mxg_vec_cache_flush(mxg_ctx* c);
 // build the apply-side structures of an adopted matrix if that has not happened yet
 int mxg_csr_materialize(mxg_csr* a);
 // y = A x through the ELL form of a short-row matrix (0 done, 1 not applicable: use mxg_csr_apply, 2 error)

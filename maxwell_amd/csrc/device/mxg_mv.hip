@@ -395,7 +395,7 @@ extern "C" int mxg_mv_create(mxg_ctx* c, int64_t nlocal, int k, int is_complex, 
   v->col0 = 0;
   v->hcols.resize(k);
   for (int j = 0; j < k; ++j) v->hcols[j] = j;
-  MXG_HIP(hipMalloc(&v->base, sizeof(double) * v->ld * k));
+  if (mxg_vec_alloc(c, sizeof(double) * v->ld * k, (void**)&v->base) != 0) { delete v; return 1; }
   MXG_HIP(hipMemsetAsync(v->base, 0, sizeof(double) * v->ld * k, c->stream));
   *out = v;
   return 0;
@@ -460,9 +460,8 @@ extern "C" int mxg_mv_destroy(mxg_mv* v) {
   if (!v) return 0;
   if (!mxg_ctx_alive(v->ctx)) { delete v; return 0; }   // context already gone: nothing to release safely
   hipSetDevice(v->ctx->device);
-  hipStreamSynchronize(v->ctx->stream);
-  if (v->owner && v->base) hipFree(v->base);
-  if (v->dcols) hipFree(v->dcols);
+  if (v->owner && v->base) mxg_vec_release(v->ctx, v->base, sizeof(double) * v->ld * v->ktotal);
+  if (v->dcols) { hipStreamSynchronize(v->ctx->stream); hipFree(v->dcols); }
   delete v;
   return 0;
 }
