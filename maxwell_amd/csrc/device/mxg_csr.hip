@@ -681,7 +681,15 @@ __global__ __launch_bounds__(CFG::SBLK / CS_RPT) void k_spmv_cs(
 __global__ void k_sum_partials(const double* __restrict__ partial, long long n, double* __restrict__ out) {
   __shared__ double lds[1024];
   double s = 0.0;
-  for (long long i = threadIdx.x; i < n; i += 1024) s += partial[i];
+  long long i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {        // eight loads in flight, added in index order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < n; i += 1024) s += partial[i];
   lds[threadIdx.x] = s;
   __syncthreads();
   for (int w = 512; w > 0; w >>= 1) {

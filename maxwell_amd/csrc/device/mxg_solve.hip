@@ -59,16 +59,15 @@ int apply_prec(mxg_ctx* c, const mxg_csr* A, const mxg_solve_opts* o, const mxg_
 // Fused CG (real scalars, Jacobi or no preconditioner): three passes per iteration and no host
 // round trip inside a chunk of iterations.
 //   1. q = A p with p.q folded into the SpMV          (mxg_dev_csr_apply_dot)
-//   2. x += a p, r -= a q, z = D^-1 r, r.z and r.r     (k_cg_update; a = rz / pq read on the device)
-//   3. p = z + b p                                     (k_cg_dir;   b = rz_new / rz read on the device)
+//   2. r -= a q, z = D^-1 r, r.z and r.r               (k_cg_update; a = rz / pq read on the device)
+//   3. x += a p, p = z + b p                           (k_cg_dir;   b = rz_new / rz read on the device)
 // All scalars live in ctx->d_result; across ranks they are all-reduced in place on the stream.
 // Every CHUNK iterations r.r comes to the host for the convergence test (unscaled 2-norm).
 // ------------------------------------------------------------------------------------------
 constexpr int CGB = 256;
 enum { S_RZ0 = 0, S_RR = 1, S_RZ1 = 2, S_PQ = 3 };   // r.r sits between the two r.z slots: one all-reduce covers both
 
-__global__ void k_cg_update(long long n, double* __restrict__ x, double* __restrict__ r,
-                            const double* __restrict__ p, const double* __restrict__ q,
+__global__ void k_cg_update(long long n, double* __restrict__ r, const double* __restrict__ q,
                             double* __restrict__ z, const double* __restrict__ diag,
                             const double* __restrict__ scal, int irz, double* __restrict__ partial,
                             double* __restrict__ zmg, const double* __restrict__ dmg, double omg) {
@@ -78,7 +77,6 @@ __global__ void k_cg_update(long long n, double* __restrict__ x, double* __restr
   double srz = 0.0, srr = 0.0;
   const long long stride = (long long)gridDim.x * CGB;
   for (long long i = (long long)blockIdx.x * CGB + threadIdx.x; i < n; i += stride) {
-    x[i] += alpha * p[i];
     const double ri = r[i] - alpha * q[i];
     r[i] = ri;
     double zi = ri;
@@ -115,12 +113,18 @@ __global__ void k_cg_reduce2(const double* __restrict__ partial, int nblocks, do
   if (threadIdx.x == 0) scal[blockIdx.x == 0 ? irz_new : S_RR] = lds[0];
 }
 
-__global__ void k_cg_dir(long long n, double* __restrict__ p, const double* __restrict__ z,
+// x += a p (the step of this iteration: p is read here anyway, the update kernel does not touch it), p = z + b p
+__global__ void k_cg_dir(long long n, double* __restrict__ p, const double* __restrict__ z, double* __restrict__ x,
                          const double* __restrict__ scal, int irz_old, int irz_new) {
-  const double den = scal[irz_old];
+  const double den = scal[irz_old], pq = scal[S_PQ];
   const double beta = den != 0.0 ? scal[irz_new] / den : 0.0;
+  const double alpha = pq != 0.0 ? den / pq : 0.0;
   const long long stride = (long long)gridDim.x * CGB;
-  for (long long i = (long long)blockIdx.x * CGB + threadIdx.x; i < n; i += stride) p[i] = z[i] + beta * p[i];
+  for (long long i = (long long)blockIdx.x * CGB + threadIdx.x; i < n; i += stride) {
+    const double po = p[i];
+    x[i] += alpha * po;
+    p[i] = z[i] + beta * po;
+  }
 }
 
 
@@ -655,8 +659,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
         MXG_TRY(allreduce(scal + S_PQ, 1));
         double* zmg = nullptr; const double* dmg = nullptr; double omg = 0.0;
         const bool first = mgprec && mg_first_step(o->mg, &zmg, &dmg, &omg);
-        hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(CGB), 0, c->stream, n, x->colptr(0), r->colptr(0),
-                           (const double*)p->colptr(0), (const double*)q->colptr(0),
+        hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(CGB), 0, c->stream, n, r->colptr(0), (const double*)q->colptr(0),
                            mgprec ? (double*)nullptr : z->colptr(0), diag, (const double*)scal, cur, c->d_partial,
                            first ? zmg : (double*)nullptr, dmg, omg);
         if (first) o->mg->first_done = true;
@@ -676,7 +679,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
           MXG_TRY(allreduce(scal + std::min(nxt, (int)S_RR), 2));   // r.z (slot nxt) and r.r, adjacent
         }
         hipLaunchKernelGGL(k_cg_dir, dim3(grid), dim3(CGB), 0, c->stream, n, p->colptr(0),
-                           (const double*)zc->colptr(0), (const double*)scal, cur, nxt);
+                           (const double*)zc->colptr(0), x->colptr(0), (const double*)scal, cur, nxt);
         cur = nxt;
       }
       MXG_HIP(hipGetLastError());
