@@ -36,6 +36,7 @@ constexpr int TL_SHORT = 8, TL_LONG = 16;      // entries of a short / long patt
 constexpr int TILE_ROWS = 126, TILE_ROWS_C = 63, TILE_WAVES = 4, TILE_MIN_RUN = 24, TILE_TPW = 2;
 constexpr int TILE_BLOCK = 64 * TILE_WAVES;
 constexpr int TILE_ORDER = 2;                  // placement of the group octets in the grid (k_spmv_tile): spread, 0.116 against 0.122 ms first / last at 256^3
+constexpr int GEN_SORT_WINDOW = 4096;          // irregular rows are sorted by length within windows of this many before grouping
 constexpr int GEN_MAXW = 40;                   // widest ELL group (35: dielectric interface rows of the FIT stencil); longer rows are "long rows"
 
 typedef double dbl2p __attribute__((ext_vector_type(2)));
@@ -564,7 +565,15 @@ void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n
   }
   P.lrows = li; P.nl_interior = (int64_t)li.size();
   P.lrows.insert(P.lrows.end(), lg.begin(), lg.end());
-  auto add_groups = [&](const std::vector<int32_t>& rows) {
+  // A group is as wide as its longest row: within windows of GEN_SORT_WINDOW consecutive irregular rows the rows are
+  // dealt to groups in order of length (stable: equal lengths stay in row order), which brings the slots from 1.30 x
+  // to 1.02 x the entries on the pillbox operators (tile product 0.124 -> 0.116 ms at 256^3); the windows keep a group's rows near each other in x.
+  auto add_groups = [&](std::vector<int32_t> rows) {
+    static const int window = getenv("MXG_TILE_SORT_WINDOW") ? atoi(getenv("MXG_TILE_SORT_WINDOW")) : GEN_SORT_WINDOW;   // experiments
+    if (window > 64)
+      for (size_t b = 0; b < rows.size(); b += (size_t)window)
+        std::stable_sort(rows.begin() + (long)b, rows.begin() + (long)std::min(rows.size(), b + (size_t)window),
+                         [&](int32_t a, int32_t c2) { return rp[a + 1] - rp[a] < rp[c2 + 1] - rp[c2]; });
     for (size_t b = 0; b < rows.size(); b += 64) {
       const size_t cnt = std::min<size_t>(64, rows.size() - b);
       int width = 0;
@@ -588,6 +597,14 @@ void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n
   add_groups(gi);
   P.ngrp_interior = (int64_t)P.ggrp.size();
   add_groups(gg);
+  if (getenv("MXG_PAT_STATS")) {
+    long long actual = 0, hist[GEN_MAXW + 1] = {0};
+    for (int32_t q : gi) { actual += rp[q + 1] - rp[q]; hist[rp[q + 1] - rp[q]]++; }
+    for (int32_t q : gg) { actual += rp[q + 1] - rp[q]; hist[rp[q + 1] - rp[q]]++; }
+    fprintf(stderr, "[mxg_tile] group rows: %lld entries in %lld slots; rows by length:", actual, (long long)P.gcol.size());
+    for (int l = 0; l <= GEN_MAXW; ++l) if (hist[l]) fprintf(stderr, " %d:%lld", l, hist[l]);
+    fprintf(stderr, "\n");
+  }
 }
 
 template <typename T>
