@@ -15,7 +15,9 @@
 namespace mx {
 
 struct MgHierarchy {
+  const Csr<double>* fine = nullptr;   // level 0 is the caller's matrix (not copied: 2.2 GB at 256^3); A[0] stays empty
   std::vector<Csr<double>> A;   // level operators, fine first
+  const Csr<double>& level(size_t l) const { return l == 0 ? *fine : A[l]; }
   std::vector<Csr<double>> P;   // P[l]: n_l x n_{l+1}
   std::vector<Csr<double>> R;   // R[l]: n_{l+1} x n_l
 };
@@ -23,7 +25,8 @@ struct MgHierarchy {
 inline MgHierarchy buildAggregationHierarchy(const Csr<double>& A0, const UVec<int64_t>& gids, int ncomp,
                                              const int n[3], int64_t minCoarse, int maxLevels) {
   MgHierarchy h;
-  h.A.push_back(A0);
+  h.fine = &A0;
+  h.A.emplace_back();
   // lattice coordinates of every fine unknown
   int64_t dims[3] = {n[0] + 1, n[1] + 1, n[2] + 1};
   const int64_t nf0 = (int64_t)gids.size();
@@ -36,8 +39,8 @@ inline MgHierarchy buildAggregationHierarchy(const Csr<double>& A0, const UVec<i
     cj[r] = (int32_t)((cell / dims[2]) % dims[1]);
     ci[r] = (int32_t)(cell / (dims[2] * dims[1]));
   }
-  while ((int)h.A.size() < maxLevels && h.A.back().nrows > minCoarse) {
-    const Csr<double>& A = h.A.back();
+  while ((int)h.A.size() < maxLevels && h.level(h.A.size() - 1).nrows > minCoarse) {
+    const Csr<double>& A = h.level(h.A.size() - 1);
     const int64_t nf = A.nrows;
     const int64_t cd[3] = {(dims[0] + 1) / 2, (dims[1] + 1) / 2, (dims[2] + 1) / 2};
     // unknowns with a zero diagonal (structurally empty rows: unused components that stay in the
@@ -88,46 +91,57 @@ inline MgHierarchy buildAggregationHierarchy(const Csr<double>& A0, const UVec<i
       for (int64_t r = 0; r < nf; ++r)
         if (agg[r] >= 0) { const int64_t q = pos[agg[r]]++; R.col[q] = (int32_t)r; R.val[q] = 1.0; }
     }
-    // Galerkin coarse operator R A P, one coarse row at a time: relabel the entries of the aggregate's fine
-    // rows (fine-row order, then storage order), sort by coarse column, sum repeated columns in that order
+    // Galerkin coarse operator R A P, one coarse row at a time: the entries of the aggregate's fine rows (fine-row
+    // order, then storage order) are relabelled and merged into a list sorted by coarse column, repeated columns
+    // summed in arrival order (= a stable sort by column followed by a left-to-right sum).  One pass: contiguous
+    // chunks of coarse rows go to per-chunk buffers, the row pointer is their prefix sum, the buffers are copied out.
     Csr<double> Ac;
     Ac.nrows = nc; Ac.ncols = nc;
     Ac.rowptr.resize(nc + 1);
     UVec<int64_t> cnt(nc);
-    auto gatherRow = [&](int64_t a, std::vector<std::pair<int32_t, double> >& buf) {
-      buf.clear();
-      for (int64_t t = R.rowptr[a]; t < R.rowptr[a + 1]; ++t) {
-        const int64_t i = R.col[t];
-        for (int64_t q = A.rowptr[i]; q < A.rowptr[i + 1]; ++q) {
-          const int32_t c = agg[A.col[q]];
-          if (c >= 0) buf.emplace_back(c, A.val[q]);
-        }
-      }
-      std::stable_sort(buf.begin(), buf.end(), [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) { return x.first < y.first; });
-      size_t w = 0;
-      for (size_t x = 0; x < buf.size(); ++x) {
-        if (w > 0 && buf[w - 1].first == buf[x].first) buf[w - 1].second += buf[x].second;
-        else buf[w++] = buf[x];
-      }
-      buf.resize(w);
-    };
+    const int64_t nchunk = std::max<int64_t>(1, std::min<int64_t>(nc, 256));
+    std::vector<std::vector<int32_t> > ccol((size_t)nchunk);
+    std::vector<std::vector<double> > cval((size_t)nchunk);
+    auto chunkStart = [&](int64_t ch) { return ch * nc / nchunk; };
 #pragma omp parallel
     {
-      std::vector<std::pair<int32_t, double> > buf;
-#pragma omp for schedule(dynamic, 1024)
-      for (int64_t a = 0; a < nc; ++a) { gatherRow(a, buf); cnt[a] = (int64_t)buf.size(); }
+      std::vector<int32_t> kc;
+      std::vector<double> kv;
+#pragma omp for schedule(dynamic, 1)
+      for (int64_t ch = 0; ch < nchunk; ++ch) {
+        std::vector<int32_t>& oc = ccol[(size_t)ch];
+        std::vector<double>& ov = cval[(size_t)ch];
+        const int64_t a0 = chunkStart(ch), a1 = chunkStart(ch + 1);
+        oc.reserve((size_t)(a1 - a0) * 8); ov.reserve((size_t)(a1 - a0) * 8);
+        for (int64_t a = a0; a < a1; ++a) {
+          kc.clear(); kv.clear();
+          for (int64_t t = R.rowptr[a]; t < R.rowptr[a + 1]; ++t) {
+            const int64_t i = R.col[t];
+            for (int64_t q = A.rowptr[i]; q < A.rowptr[i + 1]; ++q) {
+              const int32_t c = agg[A.col[q]];
+              if (c < 0) continue;
+              size_t pos = kc.size();                            // rows are short: linear search from the back
+              while (pos > 0 && kc[pos - 1] > c) --pos;
+              if (pos > 0 && kc[pos - 1] == c) kv[pos - 1] += A.val[q];
+              else { kc.insert(kc.begin() + (long)pos, c); kv.insert(kv.begin() + (long)pos, A.val[q]); }
+            }
+          }
+          cnt[a] = (int64_t)kc.size();
+          oc.insert(oc.end(), kc.begin(), kc.end());
+          ov.insert(ov.end(), kv.begin(), kv.end());
+        }
+      }
     }
     Ac.rowptr[0] = 0;
     for (int64_t a = 0; a < nc; ++a) Ac.rowptr[a + 1] = Ac.rowptr[a] + cnt[a];
     Ac.col.resize(Ac.rowptr[nc]); Ac.val.resize(Ac.rowptr[nc]);
-#pragma omp parallel
-    {
-      std::vector<std::pair<int32_t, double> > buf;
-#pragma omp for schedule(dynamic, 1024)
-      for (int64_t a = 0; a < nc; ++a) {
-        gatherRow(a, buf);
-        for (size_t x = 0; x < buf.size(); ++x) { Ac.col[Ac.rowptr[a] + x] = buf[x].first; Ac.val[Ac.rowptr[a] + x] = buf[x].second; }
-      }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t ch = 0; ch < nchunk; ++ch) {
+      const int64_t o = Ac.rowptr[chunkStart(ch)];
+      std::copy(ccol[(size_t)ch].begin(), ccol[(size_t)ch].end(), Ac.col.begin() + o);
+      std::copy(cval[(size_t)ch].begin(), cval[(size_t)ch].end(), Ac.val.begin() + o);
+      std::vector<int32_t>().swap(ccol[(size_t)ch]);
+      std::vector<double>().swap(cval[(size_t)ch]);
     }
     // coordinates of the coarse unknowns
     UVec<int32_t> ncomp_c(nc), ni(nc), nj(nc), nk(nc);

@@ -50,7 +50,7 @@ mxh_mg* mxh_mg_build_gids(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::UVe
   g->ctx = ctx;
   g->ownsA0 = A0dev == nullptr;
   for (size_t l = 0; l < h.A.size(); ++l) {
-    const mx::Csr<double>& m = h.A[l];
+    const mx::Csr<double>& m = h.level(l);
     g->A.push_back(l == 0 && A0dev ? A0dev : upload(ctx, m, true));
     g->rows.push_back(m.nrows); g->nnz.push_back(m.nnz());
   }
