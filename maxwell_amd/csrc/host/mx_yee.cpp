@@ -341,26 +341,40 @@ void YeeAssembler<S>::setMap(YeeField& F) {                     // src/MxGridFie
     canon(u, c);
     for (int comp = 0; comp < F.ncomp; ++comp) keep[w * F.ncomp + comp] = use(F, comp, c);
   }
-  int64_t count = 0;
-  for (int64_t q = 0; q < nwin * F.ncomp; ++q) count += keep[q];
-  F.gids.resize(count); F.wcell.resize(count); F.owned.resize(count);
-  count = 0;
-  for (int64_t w = 0; w < nwin; ++w) {
-    int u[3], c[3];
-    winCell(w, u);
-    canon(u, c);
-    bool own = true;   // ownership follows the canonical cell (node n of a split periodic axis is node 0)
-    for (int i = 0; i < 3; ++i) own = own && c[i] >= cfg_.boxLo[i] && c[i] < cfg_.boxHi[i];
-    for (int comp = 0; comp < F.ncomp; ++comp) {
-      const int64_t q = w * F.ncomp + comp;
-      if (keep[q]) {
-        F.lidOfWin[q] = (int32_t)count;
-        F.gids[count] = gid(F, comp, c);
-        F.wcell[count] = (int32_t)w;
-        F.owned[count] = own;
-        ++count;
-      } else {
-        F.lidOfWin[q] = -1;
+  // local ids ascend with the window cell: count per block of cells, prefix sum, fill the blocks in parallel
+  const int64_t nblk = std::max<int64_t>(1, std::min<int64_t>(nwin, 1024));
+  auto blkStart = [&](int64_t b) { return b * nwin / nblk; };
+  UVec<int64_t> first(nblk + 1);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < nblk; ++b) {
+    int64_t n = 0;
+    for (int64_t q = blkStart(b) * F.ncomp; q < blkStart(b + 1) * F.ncomp; ++q) n += keep[q];
+    first[b + 1] = n;
+  }
+  first[0] = 0;
+  for (int64_t b = 0; b < nblk; ++b) first[b + 1] += first[b];
+  const int64_t total = first[nblk];
+  F.gids.resize(total); F.wcell.resize(total); F.owned.resize(total);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < nblk; ++b) {
+    int64_t count = first[b];
+    for (int64_t w = blkStart(b); w < blkStart(b + 1); ++w) {
+      int u[3], c[3];
+      winCell(w, u);
+      canon(u, c);
+      bool own = true;   // ownership follows the canonical cell (node n of a split periodic axis is node 0)
+      for (int i = 0; i < 3; ++i) own = own && c[i] >= cfg_.boxLo[i] && c[i] < cfg_.boxHi[i];
+      for (int comp = 0; comp < F.ncomp; ++comp) {
+        const int64_t q = w * F.ncomp + comp;
+        if (keep[q]) {
+          F.lidOfWin[q] = (int32_t)count;
+          F.gids[count] = gid(F, comp, c);
+          F.wcell[count] = (int32_t)w;
+          F.owned[count] = own;
+          ++count;
+        } else {
+          F.lidOfWin[q] = -1;
+        }
       }
     }
   }
@@ -1203,14 +1217,16 @@ Csr<S> YeeAssembler<S>::multiplyOps(const std::map<std::string, Csr<S>>& ops,
 template <typename S>
 std::map<std::string, Csr<S>> YeeAssembler<S>::singleOps() const {   // MxEMOps::setSingleOps, src/MxEMOps.cpp:39-168
   std::map<std::string, Csr<S>> o;
-  o["curlE"] = curlE();
-  o["curlB"] = curlB();
-  o["divB"] = divB();
-  o["gradPsi"] = gradPsi();
+  Tick tick;
+  o["curlE"] = curlE(); tick("curlE");
+  o["curlB"] = curlB(); tick("curlB");
+  o["divB"] = divB(); tick("divB");
+  o["gradPsi"] = gradPsi(); tick("gradPsi");
   if (hasPec()) {
     o["dmA"] = fracs(B_, false);
     o["dmL"] = fracs(E_, false);
     o["dmVInv"] = fracs(P_, true);
+    tick("dm*");
   }
   if (hasDielectric() || hasPml()) {                                       // src/MxEMOps.cpp:66-77
     o["invEps"] = invEps();

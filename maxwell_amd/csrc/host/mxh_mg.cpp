@@ -1,4 +1,6 @@
 // C ABI over the multigrid setup (include/mxh.h, mxh_mg_*).
+#include <chrono>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 
@@ -45,7 +47,12 @@ mxh_mg* mxh_mg_build(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::YeeField
 mxh_mg* mxh_mg_build_gids(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::UVec<int64_t>& gids, int ncomp, const int n[3],
                           int64_t min_coarse, int max_levels, int sweeps, int coarse_sweeps, double omega,
                           double coarse_scale, mxg_csr* A0dev) {
+  const bool timing = getenv("MXH_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const auto t0 = now();
   mx::MgHierarchy h = mx::buildAggregationHierarchy(A0, gids, ncomp, n, min_coarse, max_levels);
+  const auto t1 = now();
   std::unique_ptr<mxh_mg> g(new mxh_mg());
   g->ctx = ctx;
   g->ownsA0 = A0dev == nullptr;
@@ -56,9 +63,13 @@ mxh_mg* mxh_mg_build_gids(mxg_ctx* ctx, const mx::Csr<double>& A0, const mx::UVe
   }
   for (auto& m : h.P) g->P.push_back(upload(ctx, m, false));
   for (auto& m : h.R) g->R.push_back(upload(ctx, m, false));
+  const auto t2 = now();
   if (mxg_mg_create(ctx, (int)g->A.size(), g->A.data(), g->P.data(), g->R.data(), sweeps, sweeps, coarse_sweeps,
                     omega, coarse_scale, &g->mg) != 0)
     throw std::runtime_error(std::string("mxg_mg_create: ") + mxg_last_error());
+  if (timing)
+    fprintf(stderr, "[mxh_mg] %lld rows, %d levels: hierarchy (host) %.3f s, upload + product forms %.3f s, cycle workspace %.3f s\n",
+            (long long)A0.nrows, (int)g->A.size(), secs(t0, t1), secs(t1, t2), secs(t2, now()));
   return g.release();
 }
 
