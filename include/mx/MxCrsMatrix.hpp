@@ -205,7 +205,8 @@ class MxCrsMatrix {
     if (!transA && !transB && deviceAlgebra(a, b)) {
       a.ensureDevice(false); b.ensureDevice(false);
       mxg_csr* r = nullptr;
-      MX_ABI(mxg_csr_add(a.mRowMap->getComm()->getCtx(), a.mDev, mxRe(scalarA), b.mDev, mxRe(scalarB), &r), "MxCrsMatrix::matrixMatrixAdd");
+      const double za[2] = {mxRe(scalarA), mxIm(scalarA)}, zb[2] = {mxRe(scalarB), mxIm(scalarB)};
+      MX_ABI(mxg_csr_add_z(a.mRowMap->getComm()->getCtx(), a.mDev, za, b.mDev, zb, &r), "MxCrsMatrix::matrixMatrixAdd");
       result.adoptDevice(r);
       return;
     }
@@ -221,7 +222,7 @@ class MxCrsMatrix {
   mxg_csr* getRawMatrix() const { ensureDevice(); return mDev; }
   // never re-encode this matrix (operators outside the inner loops whose encoding pass would cost more than it saves)
   void keepPlain() const { mNoCompress = true; }
-  // the setup-time products / sums of real, single-rank matrices run on the GPU (MXH_DEVICE_CHAIN=0: on the host)
+  // the setup-time products / sums of single-rank matrices (real or complex) run on the GPU (MXH_DEVICE_CHAIN=0: on the host)
   static bool deviceChainEnabled() {
     static const bool on = !(getenv("MXH_DEVICE_CHAIN") && atoi(getenv("MXH_DEVICE_CHAIN")) == 0);
     return on;
@@ -251,8 +252,7 @@ class MxCrsMatrix {
     mRows.clear();
   }
   static bool deviceAlgebra(MxCrsMatrix<Scalar> const& a, MxCrsMatrix<Scalar> const& b) {
-    return deviceChainEnabled() && !ScalarTraits<Scalar>::isComplex && !a.mDistributed && !b.mDistributed &&
-           a.mRowMap->getComm()->numProc() == 1;
+    return deviceChainEnabled() && !a.mDistributed && !b.mDistributed && a.mRowMap->getComm()->numProc() == 1;
   }
   mx::Csr<Scalar> const& host() const {
     if (!mHostValid && mBorrow) {                 // borrowed arrays: the host copy is made when somebody needs one

@@ -101,7 +101,8 @@ int mxg_csr_create(mxg_ctx* ctx, int64_t nrows, int64_t ncols_owned, int64_t ngh
                    const int64_t* rowptr, const int32_t* colidx, const double* vals,
                    int is_complex, const mxg_halo_plan* plan, mxg_csr** out);
 int mxg_csr_destroy(mxg_csr* a);
-/* Setup-time sparse algebra on the device (real matrices without ghosts), bit-identical to the host versions:
+/* Setup-time sparse algebra on the device (matrices without ghosts; both operands real or both complex), bit-identical
+ * to the host versions (include/mx/mx_sparse.hpp; complex products are (ac - bd, ad + bc), |a| is hypot(re, im)):
  *   multiply: C = A B        MxCrsMatrix::matrixMatrixMultiply (src/MxCrsMatrix.cpp:361-382; the chain of
  *                            MxUtil::Trilinos::massiveCrsMultiply, src/MxUtil.cpp:318-371)
  *   add:      C = sa A + sb B MxCrsMatrix::matrixMatrixAdd (src/MxCrsMatrix.cpp:404-457; setShift, src/MxMagWaveOp.cpp:248-255)
@@ -111,6 +112,8 @@ int mxg_csr_destroy(mxg_csr* a);
  * (NULL = not wanted): MxCrsMatrix::getLocalRow / save and the multigrid setup read them. */
 int mxg_csr_multiply(mxg_ctx* ctx, const mxg_csr* a, const mxg_csr* b, mxg_csr** out);
 int mxg_csr_add(mxg_ctx* ctx, const mxg_csr* a, double sa, const mxg_csr* b, double sb, mxg_csr** out);
+/* the same with (re, im) scalars - the Scalar arguments of matrixMatrixAdd on complex matrices */
+int mxg_csr_add_z(mxg_ctx* ctx, const mxg_csr* a, const double sa[2], const mxg_csr* b, const double sb[2], mxg_csr** out);
 int mxg_csr_purge(mxg_ctx* ctx, const mxg_csr* a, double tol, mxg_csr** out);
 int mxg_csr_download(const mxg_csr* a, int64_t* rowptr, int32_t* colidx, double* vals);
 int mxg_csr_info(const mxg_csr* a, int64_t* nrows, int64_t* ncols_owned, int64_t* nghost,

@@ -63,6 +63,7 @@ MXG_SIGNATURES = {
     "mxg_csr_destroy": (C.c_int, [vp]),
     "mxg_csr_multiply": (C.c_int, [vp, vp, vp, C.POINTER(vp)]),
     "mxg_csr_add": (C.c_int, [vp, vp, C.c_double, vp, C.c_double, C.POINTER(vp)]),
+    "mxg_csr_add_z": (C.c_int, [vp, vp, c_dp, vp, c_dp, C.POINTER(vp)]),
     "mxg_csr_purge": (C.c_int, [vp, vp, C.c_double, C.POINTER(vp)]),
     "mxg_csr_download": (C.c_int, [vp, vp, vp, vp]),
     "mxg_csr_info": (C.c_int, [vp, c_i64p, c_i64p, c_i64p, c_i64p, c_ip]),

@@ -318,7 +318,9 @@ class CsrMatrix:
 
     def add(self, sa, other, sb):    # MxCrsMatrix::matrixMatrixAdd: sa * this + sb * other
         h = C.c_void_p()
-        _chk(self.lib.mxg_csr_add(self.ctx.h, self.h, float(sa), other.h, float(sb), C.byref(h)), self.lib)
+        za = (C.c_double * 2)(complex(sa).real, complex(sa).imag)
+        zb = (C.c_double * 2)(complex(sb).real, complex(sb).imag)
+        _chk(self.lib.mxg_csr_add_z(self.ctx.h, self.h, za, other.h, zb, C.byref(h)), self.lib)
         return CsrMatrix._wrap(self.ctx, h)
 
     def purge(self, tol=1e-12):      # MxCrsMatrix::purgeZeros

@@ -848,12 +848,12 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
 // A matrix born on the device (mxg_spalg.hip): take ownership of finished CSR arrays (rowptr nrows + 1, colidx / vals
 // with 8 entries of slack, columns ascending inside a row) and build what mxg_csr_create builds around them.
 int mxg_csr_adopt_device(mxg_ctx* c, int64_t nrows, int64_t ncols, int64_t nnz, int64_t* d_rowptr, int32_t* d_colidx,
-                         double* d_vals, mxg_csr** out) {
+                         double* d_vals, int is_complex, mxg_csr** out) {
   MXG_CHECK(nrows < (int64_t)1 << 31 && ncols < (int64_t)1 << 31, "mxg_csr_adopt_device: sizes must fit int32 indices");
   mxg_csr* a = new mxg_csr();
   a->ctx = c;
   a->nrows = nrows; a->ncols_owned = ncols; a->nghost = 0; a->nnz = nnz;
-  a->is_complex = 0;
+  a->is_complex = is_complex ? 1 : 0;
   a->d_rowptr = d_rowptr; a->d_colidx = d_colidx; a->d_vals = d_vals;
   a->kernel = 0;
   a->lazy = 1;
@@ -875,15 +875,16 @@ int mxg_csr_materialize(mxg_csr* a) {
   a->nblocks = (int64_t)blk.size() - 1;
   MXG_HIP(hipMalloc(&a->d_rowblk, sizeof(int32_t) * blk.size()));
   MXG_HIP(hipMemcpyAsync(a->d_rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice, c->stream));
-  MXG_HIP(hipMalloc(&a->d_diag, sizeof(double) * std::max<int64_t>(nrows, 1)));
+  const int w = a->is_complex ? 2 : 1;
+  MXG_HIP(hipMalloc(&a->d_diag, sizeof(double) * std::max<int64_t>(nrows, 1) * w));
   if (nrows > 0) {
     hipLaunchKernelGGL(k_diag, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream,
-                       (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, (long long)nrows, 1, a->d_diag);
+                       (const long long*)a->d_rowptr, a->d_colidx, a->d_vals, (long long)nrows, w, a->d_diag);
     MXG_HIP(hipGetLastError());
   }
   MXG_HIP(hipStreamSynchronize(c->stream));
-  if (nnz > 0) MXG_TRY(build_pipe_desc(a, 10, rp.data()));
-  else { a->pipe_geo = 10; a->npipe = 0; }
+  if (nnz > 0) MXG_TRY(build_pipe_desc(a, a->is_complex ? 12 : 10, rp.data()));   // as mxg_csr_create
+  else if (!a->is_complex) { a->pipe_geo = 10; a->npipe = 0; }
   return 0;
 }
 

@@ -12,6 +12,7 @@
 //             a diagonal factor is a row / column scaling on the other factor's pattern;
 //   add       union pattern, sa * a + sb * b where both are present;
 //   purge     keeps |a| > tol.
+// Real and complex scalars (both operands of one kind).
 // These kernels run once per problem; they are latency-tolerant row loops, not bandwidth kernels.
 #include <algorithm>
 
@@ -37,9 +38,23 @@ __global__ __launch_bounds__(SA_BLOCK) void k_scan_block(const long long* __rest
   if (i < n) out[i + 1] = s[threadIdx.x];
   if (threadIdx.x == SA_BLOCK - 1) bsum[blockIdx.x] = s[threadIdx.x];
 }
-__global__ void k_scan_sums(long long* bsum, long long nb) {   // one thread: nb is nrows / 256
+// exclusive scan of the block sums in place, one workgroup: a contiguous chunk per thread, the chunk totals scanned in LDS
+// (a single thread used to walk the 80 000 sums of a 256^3 operator: 7 ms per scan, nine scans per chain)
+__global__ __launch_bounds__(1024) void k_scan_sums(long long* bsum, long long nb) {
+  __shared__ long long tot[1024];
+  const long long per = (nb + 1023) / 1024, b0 = (long long)threadIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
   long long acc = 0;
-  for (long long b = 0; b < nb; ++b) { const long long v = bsum[b]; bsum[b] = acc; acc += v; }
+  for (long long b = b0; b < b1; ++b) acc += bsum[b];
+  tot[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const long long v = (int)threadIdx.x >= off ? tot[threadIdx.x - off] : 0;
+    __syncthreads();
+    tot[threadIdx.x] += v;
+    __syncthreads();
+  }
+  acc = threadIdx.x > 0 ? tot[threadIdx.x - 1] : 0;
+  for (long long b = b0; b < b1; ++b) { const long long v = bsum[b]; bsum[b] = acc; acc += v; }
 }
 __global__ __launch_bounds__(SA_BLOCK) void k_scan_fix(long long* __restrict__ out, long long n,
                                                         const long long* __restrict__ bsum) {
@@ -53,7 +68,7 @@ int exclusive_scan(mxg_ctx* c, const long long* d_in, long long n, long long* d_
   long long* bsum = nullptr;
   MXG_HIP(hipMalloc(&bsum, sizeof(long long) * nb));
   hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SA_BLOCK), 0, c->stream, d_in, n, d_out, bsum);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1), 0, c->stream, bsum, nb);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, c->stream, bsum, nb);
   hipLaunchKernelGGL(k_scan_fix, dim3((unsigned)nb), dim3(SA_BLOCK), 0, c->stream, d_out, n, (const long long*)bsum);
   MXG_HIP(hipGetLastError());
   MXG_HIP(hipStreamSynchronize(c->stream));
@@ -72,7 +87,28 @@ __global__ __launch_bounds__(SA_BLOCK) void k_mm_upper(const long long* __restri
   ub[i] = n;
 }
 
+// values of W doubles (1: real, 2: complex as (re, im)); the complex product and sum are those std::complex<double>
+// forms on the host for finite operands - (ac - bd, ad + bc), no contraction - so that both chains agree bit for bit
+template <int W> struct Val;
+template <> struct Val<1> {
+  double x;
+  __device__ static Val ld(const double* p, long long i) { Val v; v.x = p[i]; return v; }
+  __device__ void st(double* p, long long i) const { p[i] = x; }
+  __device__ Val mul(const Val& o) const { Val v; v.x = x * o.x; return v; }
+  __device__ Val add(const Val& o) const { Val v; v.x = x + o.x; return v; }
+  __device__ double mag() const { return fabs(x); }
+};
+template <> struct Val<2> {
+  double x, y;
+  __device__ static Val ld(const double* p, long long i) { Val v; v.x = p[2 * i]; v.y = p[2 * i + 1]; return v; }
+  __device__ void st(double* p, long long i) const { p[2 * i] = x; p[2 * i + 1] = y; }
+  __device__ Val mul(const Val& o) const { Val v; v.x = x * o.x - y * o.y; v.y = x * o.y + y * o.x; return v; }
+  __device__ Val add(const Val& o) const { Val v; v.x = x + o.x; v.y = y + o.y; return v; }
+  __device__ double mag() const { return hypot(x, y); }          // std::abs(std::complex)
+};
+
 // Gustavson row: accumulate in meeting order (linear search of the row's own slice), then insertion sort by column
+template <int W>
 __global__ __launch_bounds__(SA_BLOCK) void k_mm_rows(const long long* __restrict__ arp, const int* __restrict__ aci,
                                                        const double* __restrict__ ava, const long long* __restrict__ brp,
                                                        const int* __restrict__ bci, const double* __restrict__ bva,
@@ -82,29 +118,30 @@ __global__ __launch_bounds__(SA_BLOCK) void k_mm_rows(const long long* __restric
   const long long i = (long long)blockIdx.x * SA_BLOCK + threadIdx.x;
   if (i >= nrows) return;
   int* c = tc + ub[i];
-  double* v = tv + ub[i];
+  double* v = tv + ub[i] * W;
   long long n = 0;
   for (long long p = arp[i]; p < arp[i + 1]; ++p) {
     const int k = aci[p];
-    const double a = ava[p];
+    const Val<W> a = Val<W>::ld(ava, p);
     for (long long q = brp[k]; q < brp[k + 1]; ++q) {
       const int j = bci[q];
-      const double prod = a * bva[q];
+      const Val<W> prod = a.mul(Val<W>::ld(bva, q));
       long long f = 0;
       while (f < n && c[f] != j) ++f;
-      if (f < n) v[f] += prod; else { c[n] = j; v[n] = prod; ++n; }
+      if (f < n) Val<W>::ld(v, f).add(prod).st(v, f); else { c[n] = j; prod.st(v, n); ++n; }
     }
   }
   for (long long x = 1; x < n; ++x) {
     const int cc = c[x];
-    const double vv = v[x];
+    const Val<W> vv = Val<W>::ld(v, x);
     long long y = x - 1;
-    while (y >= 0 && c[y] > cc) { c[y + 1] = c[y]; v[y + 1] = v[y]; --y; }
-    c[y + 1] = cc; v[y + 1] = vv;
+    while (y >= 0 && c[y] > cc) { c[y + 1] = c[y]; Val<W>::ld(v, y).st(v, y + 1); --y; }
+    c[y + 1] = cc; vv.st(v, y + 1);
   }
   cnt[i] = n;
 }
 
+template <int W>
 __global__ __launch_bounds__(SA_BLOCK) void k_compact(const long long* __restrict__ ub, const int* __restrict__ tc,
                                                        const double* __restrict__ tv, long long nrows,
                                                        const long long* __restrict__ crp, int* __restrict__ cci,
@@ -112,22 +149,26 @@ __global__ __launch_bounds__(SA_BLOCK) void k_compact(const long long* __restric
   const long long i = (long long)blockIdx.x * SA_BLOCK + threadIdx.x;
   if (i >= nrows) return;
   const long long n = crp[i + 1] - crp[i];
-  for (long long x = 0; x < n; ++x) { cci[crp[i] + x] = tc[ub[i] + x]; cva[crp[i] + x] = tv[ub[i] + x]; }
+  for (long long x = 0; x < n; ++x) { cci[crp[i] + x] = tc[ub[i] + x]; Val<W>::ld(tv, ub[i] + x).st(cva, crp[i] + x); }
 }
 
 // diagonal factor: rows of B scaled by d[i] (A diagonal) or entries of A scaled by d[col] (B diagonal)
+template <int W>
 __global__ __launch_bounds__(SA_BLOCK) void k_scale_rows(const long long* __restrict__ rp, const double* __restrict__ va,
                                                           const double* __restrict__ d, long long nrows,
                                                           double* __restrict__ out) {
   const long long i = (long long)blockIdx.x * SA_BLOCK + threadIdx.x;
   if (i >= nrows) return;
-  for (long long p = rp[i]; p < rp[i + 1]; ++p) out[p] = d[i] * va[p];
+  const Val<W> di = Val<W>::ld(d, i);
+  for (long long p = rp[i]; p < rp[i + 1]; ++p) di.mul(Val<W>::ld(va, p)).st(out, p);
 }
+template <int W>
 __global__ __launch_bounds__(SA_BLOCK) void k_scale_cols(const int* __restrict__ ci, const double* __restrict__ va,
                                                           const double* __restrict__ d, long long nnz,
                                                           double* __restrict__ out) {
   const long long stride = (long long)gridDim.x * SA_BLOCK;
-  for (long long p = (long long)blockIdx.x * SA_BLOCK + threadIdx.x; p < nnz; p += stride) out[p] = va[p] * d[ci[p]];
+  for (long long p = (long long)blockIdx.x * SA_BLOCK + threadIdx.x; p < nnz; p += stride)
+    Val<W>::ld(va, p).mul(Val<W>::ld(d, ci[p])).st(out, p);
 }
 
 // ---- add: count, then fill (two-pointer merge of the sorted rows)
@@ -145,32 +186,35 @@ __global__ __launch_bounds__(SA_BLOCK) void k_add_count(const long long* __restr
   }
   cnt[i] = n;
 }
+template <int W>
 __global__ __launch_bounds__(SA_BLOCK) void k_add_fill(const long long* __restrict__ arp, const int* __restrict__ aci,
-                                                        const double* __restrict__ ava, double sa,
+                                                        const double* __restrict__ ava, Val<W> sa,
                                                         const long long* __restrict__ brp, const int* __restrict__ bci,
-                                                        const double* __restrict__ bva, double sb, long long nrows,
+                                                        const double* __restrict__ bva, Val<W> sb, long long nrows,
                                                         const long long* __restrict__ crp, int* __restrict__ cci,
                                                         double* __restrict__ cva) {
   const long long i = (long long)blockIdx.x * SA_BLOCK + threadIdx.x;
   if (i >= nrows) return;
   long long p = arp[i], pe = arp[i + 1], q = brp[i], qe = brp[i + 1], w = crp[i];
   while (p < pe || q < qe) {
-    if (q >= qe || (p < pe && aci[p] < bci[q])) { cci[w] = aci[p]; cva[w] = sa * ava[p]; ++p; }
-    else if (p >= pe || bci[q] < aci[p]) { cci[w] = bci[q]; cva[w] = sb * bva[q]; ++q; }
-    else { cci[w] = aci[p]; cva[w] = sa * ava[p] + sb * bva[q]; ++p; ++q; }
+    if (q >= qe || (p < pe && aci[p] < bci[q])) { cci[w] = aci[p]; sa.mul(Val<W>::ld(ava, p)).st(cva, w); ++p; }
+    else if (p >= pe || bci[q] < aci[p]) { cci[w] = bci[q]; sb.mul(Val<W>::ld(bva, q)).st(cva, w); ++q; }
+    else { cci[w] = aci[p]; sa.mul(Val<W>::ld(ava, p)).add(sb.mul(Val<W>::ld(bva, q))).st(cva, w); ++p; ++q; }
     ++w;
   }
 }
 
 // ---- purge
+template <int W>
 __global__ __launch_bounds__(SA_BLOCK) void k_purge_count(const long long* __restrict__ rp, const double* __restrict__ va,
                                                            double tol, long long nrows, long long* __restrict__ cnt) {
   const long long i = (long long)blockIdx.x * SA_BLOCK + threadIdx.x;
   if (i >= nrows) return;
   long long n = 0;
-  for (long long p = rp[i]; p < rp[i + 1]; ++p) if (fabs(va[p]) > tol) ++n;
+  for (long long p = rp[i]; p < rp[i + 1]; ++p) if (Val<W>::ld(va, p).mag() > tol) ++n;
   cnt[i] = n;
 }
+template <int W>
 __global__ __launch_bounds__(SA_BLOCK) void k_purge_fill(const long long* __restrict__ rp, const int* __restrict__ ci,
                                                           const double* __restrict__ va, double tol, long long nrows,
                                                           const long long* __restrict__ crp, int* __restrict__ cci,
@@ -178,8 +222,10 @@ __global__ __launch_bounds__(SA_BLOCK) void k_purge_fill(const long long* __rest
   const long long i = (long long)blockIdx.x * SA_BLOCK + threadIdx.x;
   if (i >= nrows) return;
   long long w = crp[i];
-  for (long long p = rp[i]; p < rp[i + 1]; ++p)
-    if (fabs(va[p]) > tol) { cci[w] = ci[p]; cva[w] = va[p]; ++w; }
+  for (long long p = rp[i]; p < rp[i + 1]; ++p) {
+    const Val<W> v = Val<W>::ld(va, p);
+    if (v.mag() > tol) { cci[w] = ci[p]; v.st(cva, w); ++w; }
+  }
 }
 
 __global__ void k_is_diagonal(const long long* __restrict__ rp, const int* __restrict__ ci, long long nrows, int* flag) {
@@ -224,7 +270,7 @@ int is_diagonal(mxg_ctx* c, const mxg_csr* a, bool* out) {
 
 int check_operands(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, const char* what) {
   MXG_CHECK(c && a && b, "%s: NULL argument", what);
-  MXG_CHECK(!a->is_complex && !b->is_complex, "%s: real matrices only", what);
+  MXG_CHECK(a->is_complex == b->is_complex, "%s: one operand is real, the other complex", what);
   MXG_CHECK(a->nghost == 0 && b->nghost == 0 && a->nneigh == 0 && b->nneigh == 0,
             "%s: row-partitioned matrices are formed on the window by the host assembler", what);
   return 0;
@@ -234,7 +280,7 @@ int check_operands(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, const char* w
 
 // defined in mxg_csr.hip: wrap finished device CSR arrays (rowptr nrows + 1, colidx / vals with 8 entries of slack)
 int mxg_csr_adopt_device(mxg_ctx* c, int64_t nrows, int64_t ncols, int64_t nnz, int64_t* d_rowptr, int32_t* d_colidx,
-                         double* d_vals, mxg_csr** out);
+                         double* d_vals, int is_complex, mxg_csr** out);
 
 extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, mxg_csr** out) {
   DevPool pool;
@@ -245,6 +291,7 @@ extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, 
             (long long)b->nrows);
   MXG_HIP(hipSetDevice(c->device));
   const long long nrows = a->nrows;
+  const int cx = a->is_complex ? 1 : 0, w = cx ? 2 : 1;
   bool adiag = false, bdiag = false;
   MXG_TRY(is_diagonal(c, a, &adiag));
   if (!adiag) MXG_TRY(is_diagonal(c, b, &bdiag));
@@ -254,20 +301,26 @@ extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, 
     int64_t* rp = nullptr; int32_t* ci = nullptr; double* va = nullptr;
     MXG_TRY(pool.alloc(&rp, sizeof(int64_t) * (pat->nrows + 1)));
     MXG_TRY(pool.alloc(&ci, sizeof(int32_t) * (pat->nnz + 8)));
-    MXG_TRY(pool.alloc(&va, sizeof(double) * (pat->nnz + 8)));
+    MXG_TRY(pool.alloc(&va, sizeof(double) * (pat->nnz + 8) * w));
     MXG_HIP(hipMemsetAsync(ci, 0, sizeof(int32_t) * (pat->nnz + 8), c->stream));
-    MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (pat->nnz + 8), c->stream));
+    MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (pat->nnz + 8) * w, c->stream));
     MXG_HIP(hipMemcpyAsync(rp, pat->d_rowptr, sizeof(int64_t) * (pat->nrows + 1), hipMemcpyDeviceToDevice, c->stream));
     if (pat->nnz > 0) MXG_HIP(hipMemcpyAsync(ci, pat->d_colidx, sizeof(int32_t) * pat->nnz, hipMemcpyDeviceToDevice, c->stream));
-    if (adiag)
-      hipLaunchKernelGGL(k_scale_rows, dim3(rows_grid(pat->nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)b->d_rowptr,
-                         (const double*)b->d_vals, (const double*)a->d_vals, (long long)b->nrows, va);
-    else if (pat->nnz > 0)
-      hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)std::min<long long>((pat->nnz + SA_BLOCK - 1) / SA_BLOCK, 65535)), dim3(SA_BLOCK), 0,
-                         c->stream, (const int*)a->d_colidx, (const double*)a->d_vals, (const double*)b->d_vals, (long long)a->nnz, va);
+    const unsigned gcols = (unsigned)std::min<long long>((pat->nnz + SA_BLOCK - 1) / SA_BLOCK, 65535);
+    if (adiag) {
+      if (cx) hipLaunchKernelGGL(k_scale_rows<2>, dim3(rows_grid(pat->nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)b->d_rowptr,
+                                 (const double*)b->d_vals, (const double*)a->d_vals, (long long)b->nrows, va);
+      else hipLaunchKernelGGL(k_scale_rows<1>, dim3(rows_grid(pat->nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)b->d_rowptr,
+                              (const double*)b->d_vals, (const double*)a->d_vals, (long long)b->nrows, va);
+    } else if (pat->nnz > 0) {
+      if (cx) hipLaunchKernelGGL(k_scale_cols<2>, dim3(gcols), dim3(SA_BLOCK), 0, c->stream, (const int*)a->d_colidx,
+                                 (const double*)a->d_vals, (const double*)b->d_vals, (long long)a->nnz, va);
+      else hipLaunchKernelGGL(k_scale_cols<1>, dim3(gcols), dim3(SA_BLOCK), 0, c->stream, (const int*)a->d_colidx,
+                              (const double*)a->d_vals, (const double*)b->d_vals, (long long)a->nnz, va);
+    }
     MXG_HIP(hipGetLastError());
     pool.keep(rp); pool.keep(ci); pool.keep(va);
-  return mxg_csr_adopt_device(c, pat->nrows, adiag ? b->ncols_owned : b->ncols_owned, pat->nnz, rp, ci, va, out);
+    return mxg_csr_adopt_device(c, pat->nrows, b->ncols_owned, pat->nnz, rp, ci, va, cx, out);
   }
   long long *ub_cnt = nullptr, *ub = nullptr, *cnt = nullptr;
   MXG_TRY(pool.alloc(&ub_cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
@@ -280,10 +333,13 @@ extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, 
   MXG_HIP(hipMemcpy(&total, ub + nrows, sizeof(long long), hipMemcpyDeviceToHost));
   int* tc = nullptr; double* tv = nullptr;
   MXG_TRY(pool.alloc(&tc, sizeof(int) * std::max<long long>(total, 1)));
-  MXG_TRY(pool.alloc(&tv, sizeof(double) * std::max<long long>(total, 1)));
-  hipLaunchKernelGGL(k_mm_rows, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
-                     (const int*)a->d_colidx, (const double*)a->d_vals, (const long long*)b->d_rowptr, (const int*)b->d_colidx,
-                     (const double*)b->d_vals, nrows, (const long long*)ub, tc, tv, cnt);
+  MXG_TRY(pool.alloc(&tv, sizeof(double) * std::max<long long>(total, 1) * w));
+  if (cx) hipLaunchKernelGGL(k_mm_rows<2>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
+                             (const int*)a->d_colidx, (const double*)a->d_vals, (const long long*)b->d_rowptr, (const int*)b->d_colidx,
+                             (const double*)b->d_vals, nrows, (const long long*)ub, tc, tv, cnt);
+  else hipLaunchKernelGGL(k_mm_rows<1>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
+                          (const int*)a->d_colidx, (const double*)a->d_vals, (const long long*)b->d_rowptr, (const int*)b->d_colidx,
+                          (const double*)b->d_vals, nrows, (const long long*)ub, tc, tv, cnt);
   MXG_HIP(hipGetLastError());
   int64_t* rp = nullptr;
   MXG_TRY(pool.alloc(&rp, sizeof(int64_t) * (nrows + 1)));
@@ -292,23 +348,28 @@ extern "C" int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, 
   MXG_HIP(hipMemcpy(&nnz, rp + nrows, sizeof(long long), hipMemcpyDeviceToHost));
   int32_t* ci = nullptr; double* va = nullptr;
   MXG_TRY(pool.alloc(&ci, sizeof(int32_t) * (nnz + 8)));
-  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8) * w));
   MXG_HIP(hipMemsetAsync(ci, 0, sizeof(int32_t) * (nnz + 8), c->stream));
-  MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8), c->stream));
-  hipLaunchKernelGGL(k_compact, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)ub, (const int*)tc,
-                     (const double*)tv, nrows, (const long long*)rp, ci, va);
+  MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8) * w, c->stream));
+  if (cx) hipLaunchKernelGGL(k_compact<2>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)ub, (const int*)tc,
+                             (const double*)tv, nrows, (const long long*)rp, ci, va);
+  else hipLaunchKernelGGL(k_compact<1>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)ub, (const int*)tc,
+                          (const double*)tv, nrows, (const long long*)rp, ci, va);
   MXG_HIP(hipGetLastError());
   MXG_HIP(hipStreamSynchronize(c->stream));
   pool.keep(rp); pool.keep(ci); pool.keep(va);
-  return mxg_csr_adopt_device(c, nrows, b->ncols_owned, nnz, rp, ci, va, out);
+  return mxg_csr_adopt_device(c, nrows, b->ncols_owned, nnz, rp, ci, va, cx, out);
 }
 
-extern "C" int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_csr* b, double sb, mxg_csr** out) {
+extern "C" int mxg_csr_add_z(mxg_ctx* c, const mxg_csr* a, const double sa[2], const mxg_csr* b, const double sb[2], mxg_csr** out) {
   DevPool pool;
+  MXG_CHECK(a && b && sa && sb, "mxg_csr_add: NULL argument");
   MxgSetupTrace trace("mxg_csr_add (nnz a)", a->nnz);
   MXG_TRY(check_operands(c, a, b, "mxg_csr_add"));
   MXG_CHECK(out, "mxg_csr_add: NULL argument");
   MXG_CHECK(a->nrows == b->nrows && a->ncols_owned == b->ncols_owned, "mxg_csr_add: shapes differ");
+  const int cx = a->is_complex ? 1 : 0, w = cx ? 2 : 1;
+  MXG_CHECK(cx || (sa[1] == 0.0 && sb[1] == 0.0), "mxg_csr_add: complex scalars on real matrices");
   MXG_HIP(hipSetDevice(c->device));
   const long long nrows = a->nrows;
   long long* cnt = nullptr;
@@ -322,16 +383,29 @@ extern "C" int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_cs
   MXG_HIP(hipMemcpy(&nnz, rp + nrows, sizeof(long long), hipMemcpyDeviceToHost));
   int32_t* ci = nullptr; double* va = nullptr;
   MXG_TRY(pool.alloc(&ci, sizeof(int32_t) * (nnz + 8)));
-  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8) * w));
   MXG_HIP(hipMemsetAsync(ci, 0, sizeof(int32_t) * (nnz + 8), c->stream));
-  MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8), c->stream));
-  hipLaunchKernelGGL(k_add_fill, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
-                     (const int*)a->d_colidx, (const double*)a->d_vals, sa, (const long long*)b->d_rowptr,
-                     (const int*)b->d_colidx, (const double*)b->d_vals, sb, nrows, (const long long*)rp, ci, va);
+  MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8) * w, c->stream));
+  if (cx) {
+    Val<2> za, zb; za.x = sa[0]; za.y = sa[1]; zb.x = sb[0]; zb.y = sb[1];
+    hipLaunchKernelGGL(k_add_fill<2>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
+                       (const int*)a->d_colidx, (const double*)a->d_vals, za, (const long long*)b->d_rowptr,
+                       (const int*)b->d_colidx, (const double*)b->d_vals, zb, nrows, (const long long*)rp, ci, va);
+  } else {
+    Val<1> ra, rb; ra.x = sa[0]; rb.x = sb[0];
+    hipLaunchKernelGGL(k_add_fill<1>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
+                       (const int*)a->d_colidx, (const double*)a->d_vals, ra, (const long long*)b->d_rowptr,
+                       (const int*)b->d_colidx, (const double*)b->d_vals, rb, nrows, (const long long*)rp, ci, va);
+  }
   MXG_HIP(hipGetLastError());
   MXG_HIP(hipStreamSynchronize(c->stream));
   pool.keep(rp); pool.keep(ci); pool.keep(va);
-  return mxg_csr_adopt_device(c, nrows, a->ncols_owned, nnz, rp, ci, va, out);
+  return mxg_csr_adopt_device(c, nrows, a->ncols_owned, nnz, rp, ci, va, cx, out);
+}
+
+extern "C" int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_csr* b, double sb, mxg_csr** out) {
+  const double za[2] = {sa, 0.0}, zb[2] = {sb, 0.0};
+  return mxg_csr_add_z(c, a, za, b, zb, out);
 }
 
 extern "C" int mxg_csr_purge(mxg_ctx* c, const mxg_csr* a, double tol, mxg_csr** out) {
@@ -343,8 +417,11 @@ extern "C" int mxg_csr_purge(mxg_ctx* c, const mxg_csr* a, double tol, mxg_csr**
   const long long nrows = a->nrows;
   long long* cnt = nullptr;
   MXG_TRY(pool.alloc(&cnt, sizeof(long long) * std::max<long long>(nrows, 1)));
-  hipLaunchKernelGGL(k_purge_count, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
-                     (const double*)a->d_vals, tol, nrows, cnt);
+  const int cx = a->is_complex ? 1 : 0, w = cx ? 2 : 1;
+  if (cx) hipLaunchKernelGGL(k_purge_count<2>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
+                             (const double*)a->d_vals, tol, nrows, cnt);
+  else hipLaunchKernelGGL(k_purge_count<1>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
+                          (const double*)a->d_vals, tol, nrows, cnt);
   int64_t* rp = nullptr;
   MXG_TRY(pool.alloc(&rp, sizeof(int64_t) * (nrows + 1)));
   MXG_TRY(exclusive_scan(c, cnt, nrows, (long long*)rp));
@@ -352,15 +429,17 @@ extern "C" int mxg_csr_purge(mxg_ctx* c, const mxg_csr* a, double tol, mxg_csr**
   MXG_HIP(hipMemcpy(&nnz, rp + nrows, sizeof(long long), hipMemcpyDeviceToHost));
   int32_t* ci = nullptr; double* va = nullptr;
   MXG_TRY(pool.alloc(&ci, sizeof(int32_t) * (nnz + 8)));
-  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8)));
+  MXG_TRY(pool.alloc(&va, sizeof(double) * (nnz + 8) * w));
   MXG_HIP(hipMemsetAsync(ci, 0, sizeof(int32_t) * (nnz + 8), c->stream));
-  MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8), c->stream));
-  hipLaunchKernelGGL(k_purge_fill, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
-                     (const int*)a->d_colidx, (const double*)a->d_vals, tol, nrows, (const long long*)rp, ci, va);
+  MXG_HIP(hipMemsetAsync(va, 0, sizeof(double) * (nnz + 8) * w, c->stream));
+  if (cx) hipLaunchKernelGGL(k_purge_fill<2>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
+                             (const int*)a->d_colidx, (const double*)a->d_vals, tol, nrows, (const long long*)rp, ci, va);
+  else hipLaunchKernelGGL(k_purge_fill<1>, dim3(rows_grid(nrows)), dim3(SA_BLOCK), 0, c->stream, (const long long*)a->d_rowptr,
+                          (const int*)a->d_colidx, (const double*)a->d_vals, tol, nrows, (const long long*)rp, ci, va);
   MXG_HIP(hipGetLastError());
   MXG_HIP(hipStreamSynchronize(c->stream));
   pool.keep(rp); pool.keep(ci); pool.keep(va);
-  return mxg_csr_adopt_device(c, nrows, a->ncols_owned, nnz, rp, ci, va, out);
+  return mxg_csr_adopt_device(c, nrows, a->ncols_owned, nnz, rp, ci, va, cx, out);
 }
 
 // host copies of the CSR arrays (rowptr nrows + 1, colidx / vals nnz entries; NULL = not wanted)

@@ -204,19 +204,32 @@ static mx::Csr<S> to_host(const mxg_csr* a) {
 static int from_host(mxg_ctx* c, const mx::Csr<double>& m, mxg_csr** out) {
   return mxg_csr_create(c, m.nrows, m.ncols, 0, m.rowptr.data(), m.col.data(), m.val.data(), 0, nullptr, out);
 }
+static int from_host(mxg_ctx* c, const mx::Csr<std::complex<double> >& m, mxg_csr** out) {
+  return mxg_csr_create(c, m.nrows, m.ncols, 0, m.rowptr.data(), m.col.data(), reinterpret_cast<const double*>(m.val.data()), 1, nullptr, out);
+}
 
 extern "C" {
 
+// the host versions of include/mx/mx_sparse.hpp ARE the definition the device kernels reproduce
 int mxg_csr_multiply(mxg_ctx* c, const mxg_csr* a, const mxg_csr* b, mxg_csr** out) {
-  CHECK(!a->is_complex && !b->is_complex, "mxg_csr_multiply: real matrices only");
+  CHECK(a->is_complex == b->is_complex, "mxg_csr_multiply: one operand is real, the other complex");
+  if (a->is_complex) return from_host(c, mx::multiply(to_host<std::complex<double> >(a), to_host<std::complex<double> >(b)), out);
   return from_host(c, mx::multiply(to_host<double>(a), to_host<double>(b)), out);
 }
+int mxg_csr_add_z(mxg_ctx* c, const mxg_csr* a, const double sa[2], const mxg_csr* b, const double sb[2], mxg_csr** out) {
+  CHECK(a->is_complex == b->is_complex, "mxg_csr_add: one operand is real, the other complex");
+  if (a->is_complex)
+    return from_host(c, mx::add(to_host<std::complex<double> >(a), std::complex<double>(sa[0], sa[1]), to_host<std::complex<double> >(b),
+                                std::complex<double>(sb[0], sb[1])), out);
+  CHECK(sa[1] == 0.0 && sb[1] == 0.0, "mxg_csr_add: complex scalars on real matrices");
+  return from_host(c, mx::add(to_host<double>(a), sa[0], to_host<double>(b), sb[0]), out);
+}
 int mxg_csr_add(mxg_ctx* c, const mxg_csr* a, double sa, const mxg_csr* b, double sb, mxg_csr** out) {
-  CHECK(!a->is_complex && !b->is_complex, "mxg_csr_add: real matrices only");
-  return from_host(c, mx::add(to_host<double>(a), sa, to_host<double>(b), sb), out);
+  const double za[2] = {sa, 0.0}, zb[2] = {sb, 0.0};
+  return mxg_csr_add_z(c, a, za, b, zb, out);
 }
 int mxg_csr_purge(mxg_ctx* c, const mxg_csr* a, double, mxg_csr** out) {
-  CHECK(!a->is_complex, "mxg_csr_purge: real matrices only");
+  if (a->is_complex) return from_host(c, mx::purge(to_host<std::complex<double> >(a)), out);
   return from_host(c, mx::purge(to_host<double>(a)), out);
 }
 

@@ -194,3 +194,97 @@ def test_device_chain_on_the_window_of_a_decomposed_grid(ctx, nranks):
         seen += len(pos)
         dev.close(); host.close()
     assert seen == A.shape[0]
+
+
+def _golden(name):
+    root = os.path.dirname(os.path.abspath(__file__))
+    return open(os.path.join(root, "golden", name)).read()
+
+
+def _complex_decks():
+    lossy = _golden("dsphmsph.mx").replace("eps off diag = [0.0, 0.0, 0.0]", "eps off diag = [0.0, 0.0, 0.0]\n    loss tangent = 0.001")
+    lossy = lossy.replace("resolution = [12, 12, 12]", "resolution = [10, 10, 10]")
+    bloch = _golden("fiber.mx").replace("resolution = [2, 12, 12]", "resolution = [4, 10, 10]")
+    lossymu = _golden("magsph.mx").replace("mu off diag = [0.1, -0.2, 0.3]", "mu off diag = [0.1, -0.2, 0.3]\n    loss tangent = 0.02")
+    lossymu = lossymu.replace("resolution = [10, 10, 10]", "resolution = [8, 8, 8]")
+    return {"lossy dielectric": lossy, "bloch phases": bloch, "lossy mu": lossymu}
+
+
+@pytest.mark.parametrize("case", ["lossy dielectric", "bloch phases", "lossy mu"])
+def test_device_operator_chain_complex_scalars(ctx, case):
+    """Row f2 for complex scalars (loss tangents, Bloch phases): the chain of MxMagWaveOp::initMatrices formed by the
+    complex instances of mxg_csr_multiply / add / purge - bit-identical to the host chain of YeeAssembler<complex>
+    (include/mx/mx_sparse.hpp on std::complex) and equal, entry for entry, to the complex ORACLE's operators."""
+    from oracle import mxdeck
+    text = _complex_decks()[case]
+    prob = mx.Problem(text=text)
+    assert prob.is_complex
+    oracle = mxdeck.Deck(text).sim().wave_ops()
+    have = lambda nm: nm in oracle
+    ops = {}
+    for nm in ("curlE", "curlB", "divB", "gradPsi", "dmA", "dmL", "dmVInv", "invEps", "invEpsVolAve", "mu", "invMuVolAve"):
+        if have(nm):
+            m = prob.op(nm).tocsr()
+            assert np.iscomplexobj(m.data)
+            ops[nm] = mx.CsrMatrix.from_scipy(ctx, m)
+            assert ops[nm].is_complex
+    opt = lambda names: [nm for nm in names if nm in ops]
+    curlcurl = _chain(ops, opt(["curlB", "invEps", "dmL", "curlE"]))
+    assert curlcurl.is_complex
+    _same(curlcurl, prob.op("curlCurl"))
+    _same_values(curlcurl, oracle["curlCurl"])
+    graddiv = _chain(ops, opt(["mu", "dmA", "divB", "dmVInv", "invMuVolAve", "invEpsVolAve"]) + (["invMuVolAve"] if "invMuVolAve" in ops else []) +
+                     opt(["gradPsi", "mu", "dmA"]))
+    _same(graddiv, prob.op("gradDiv"))
+    _same_values(graddiv, oracle["gradDiv"])
+    veclapl = curlcurl.add(1.0, graddiv, -1.0).purge(1e-12)
+    _same(veclapl, prob.op("vecLapl"))
+    _same(veclapl, oracle["vecLapl"])
+    mrhs = prob.op("mRhs").tocsr()
+    shift = 1.25
+    shifted = veclapl.add(1.0, mx.CsrMatrix.from_scipy(ctx, mrhs), -shift)
+    want = (prob.op("vecLapl") - shift * mrhs).tocsr(); want.sort_indices()
+    got = shifted.to_scipy(); got.sort_indices()
+    d = got - want
+    assert d.nnz == 0 or np.abs(d.data).max() == 0.0
+    # a complex scalar of matrixMatrixAdd (mxg_csr_add_z): (a + i b) A + B against numpy on the union pattern
+    z = veclapl.add(0.5 + 0.25j, mx.CsrMatrix.from_scipy(ctx, mrhs), -1.0j).to_scipy()
+    V = prob.op("vecLapl").tocsr()
+    zw = ((0.5 + 0.25j) * V + (-1.0j) * mrhs).tocsr()
+    dz = z - zw
+    assert dz.nnz == 0 or np.abs(dz.data).max() <= 4e-16 * np.abs(zw.data).max()
+    # the device-born complex matrix multiplies like the host-born one, bit for bit
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, veclapl.ncols) + 1j * rng.uniform(-1, 1, veclapl.ncols)
+    X = mx.MultiVec.from_numpy(ctx, x)
+    Y1 = mx.MultiVec(ctx, veclapl.nrows, 1, is_complex=True); Y2 = mx.MultiVec(ctx, veclapl.nrows, 1, is_complex=True)
+    veclapl.apply(X, Y1)
+    mx.CsrMatrix.from_scipy(ctx, V).apply(X, Y2)
+    assert np.array_equal(Y1.to_numpy(), Y2.to_numpy())
+
+
+def test_complex_eigen_solve_with_the_chain_formed_on_the_device(ctx):
+    """A lossy-dielectric deck solved twice in child processes, operator chain on the host (MXH_DEVICE_CHAIN=0) and on
+    the device (default): the matrices are the same bit for bit, so are the eigenvalues and the iteration counts."""
+    import json, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = _complex_decks()["lossy dielectric"]
+    with tempfile.NamedTemporaryFile("w", suffix=".mx", delete=False) as f:
+        f.write(text)
+        deck = f.name
+    code = ("import sys, json; sys.path.insert(0, %r); import numpy as np; import maxwell_amd as mx\n"
+            "ctx = mx.Ctx(0); prob = mx.Problem(path=%r); s = prob.solver(ctx); n = s.solve(); st = s.stats()\n"
+            "print('RESULT ' + json.dumps(dict(k2=[[s.result(i)['k2'].real, s.result(i)['k2'].imag] for i in range(n)], vec=st['vec_iters'], sca=st['sca_iters'])))\n"
+            % (root, deck))
+    outs = {}
+    try:
+        for mode in ("0", "1"):
+            env = dict(os.environ, MXH_DEVICE_CHAIN=mode)
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+            assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+            line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+            outs[mode] = json.loads(line[7:])
+    finally:
+        os.unlink(deck)
+    assert len(outs["0"]["k2"]) >= 1
+    assert outs["0"] == outs["1"], outs
