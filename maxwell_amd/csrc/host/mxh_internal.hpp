@@ -30,5 +30,8 @@ void mxh_set_error(const std::string& s);
 std::shared_ptr<const mx::Shape> mxh_parse_shape(const char* spec);
 const mx::Csr<double>& mxh_sim_shifted_matrix(mxh_sim* s, double shift);
 void mxh_sim_ensure_chain(mxh_sim* s);
+// the operator chain formed on the GPU of `ctx` from the single operators in `ops` (mxh_sim.cpp); S = double or std::complex<double>
+template <typename S>
+void mxh_device_chain(mxg_ctx* ctx, const mx::YeeAssembler<S>& a, std::map<std::string, mx::Csr<S> >& ops);
 
 #endif

@@ -237,7 +237,7 @@ void mxh_sim_ensure_chain(mxh_sim* s) {
 // The operator chain of a sim that holds only its single operators, formed on the GPU of `ctx` with mxg_csr_multiply /
 // add / purge (bit-identical to the host chain, tests/test_spalg_gpu.py) and read back into sim->ops: the order of
 // YeeAssembler::waveOps (src/MxMagWaveOp.cpp:138-245).  This is how a rank of a decomposed grid gets the products on
-// its box + halo window (row f2 on config 4); real problems (the device algebra is real).
+// its box + halo window (row f2 on config 4), for real and complex problems.
 namespace {
 struct DevMat {
   mxg_csr* h = nullptr;
@@ -249,17 +249,82 @@ struct DevMat {
 void dev_check(int rc, const char* what) {
   if (rc != 0) throw std::runtime_error(std::string(what) + ": " + mxg_last_error());
 }
-mx::Csr<double> dev_download(const mxg_csr* h) {
+template <typename S>
+mx::Csr<S> dev_download(const mxg_csr* h) {
   int64_t nr = 0, nc = 0, ng = 0, nz = 0;
   int cx = 0;
   dev_check(mxg_csr_info(h, &nr, &nc, &ng, &nz, &cx), "mxg_csr_info");
-  mx::Csr<double> m;
+  if ((cx != 0) != (sizeof(S) == 2 * sizeof(double))) throw std::runtime_error("device chain: scalar type mismatch");
+  mx::Csr<S> m;
   m.nrows = nr; m.ncols = nc;
   m.rowptr.resize(nr + 1); m.col.resize(nz); m.val.resize(nz);
-  dev_check(mxg_csr_download(h, m.rowptr.data(), m.col.data(), m.val.data()), "mxg_csr_download");
+  dev_check(mxg_csr_download(h, m.rowptr.data(), m.col.data(), reinterpret_cast<double*>(m.val.data())), "mxg_csr_download");
   return m;
 }
 }  // namespace
+
+// the chain for either scalar type: `ops` holds the single operators on entry, the products are added to it
+template <typename S>
+void mxh_device_chain(mxg_ctx* ctx, const mx::YeeAssembler<S>& a, std::map<std::string, mx::Csr<S> >& ops) {
+  const int cx = sizeof(S) == 2 * sizeof(double) ? 1 : 0;
+  const bool pec = a.hasPec(), diel = a.hasDielectric(), mag = a.hasMu();
+  std::map<std::string, std::unique_ptr<DevMat> > dev;
+  auto get = [&](const std::string& nm) -> mxg_csr* {            // upload a single operator on first use
+    auto it = dev.find(nm);
+    if (it == dev.end()) {
+      const mx::Csr<S>& m = ops.at(nm);
+      std::unique_ptr<DevMat> d(new DevMat());
+      dev_check(mxg_csr_create(ctx, m.nrows, m.ncols, 0, m.rowptr.data(), m.col.data(), reinterpret_cast<const double*>(m.val.data()), cx,
+                               nullptr, &d->h), "mxg_csr_create");
+      it = dev.emplace(nm, std::move(d)).first;
+    }
+    return it->second->h;
+  };
+  auto chain = [&](const std::vector<std::string>& names, const std::string& out) {   // massiveCrsMultiply, src/MxUtil.cpp:318-371
+    std::unique_ptr<DevMat> res;
+    const mxg_csr* cur = get(names[0]);
+    for (size_t i = 1; i < names.size(); ++i) {
+      std::unique_ptr<DevMat> nx(new DevMat());
+      dev_check(mxg_csr_multiply(ctx, get(names[i]), cur, &nx->h), "mxg_csr_multiply");
+      res = std::move(nx);
+      cur = res->h;
+    }
+    if (!res) throw std::runtime_error("mxh_sim_device_chain: a chain needs two factors");
+    dev[out] = std::move(res);
+  };
+  auto opt = [&](std::vector<std::string>& v, const char* nm) { if (pec) v.push_back(nm); };
+  std::vector<std::string> names;
+  names = {"curlB"}; if (diel) names.push_back("invEps"); opt(names, "dmL"); names.push_back("curlE");
+  chain(names, "curlCurl");
+  names.clear(); if (mag) names.push_back("mu"); opt(names, "dmA"); names.push_back("divB"); opt(names, "dmVInv");
+  if (mag) names.push_back("invMuVolAve");
+  if (diel) names.push_back("invEpsVolAve");
+  if (mag) names.push_back("invMuVolAve");
+  names.push_back("gradPsi"); if (mag) names.push_back("mu"); opt(names, "dmA");
+  chain(names, "gradDiv");
+  {
+    DevMat sum;
+    dev_check(mxg_csr_add(ctx, dev.at("curlCurl")->h, 1.0, dev.at("gradDiv")->h, -1.0, &sum.h), "mxg_csr_add");
+    std::unique_ptr<DevMat> vl(new DevMat());
+    dev_check(mxg_csr_purge(ctx, sum.h, 1.0e-12, &vl->h), "mxg_csr_purge");
+    dev["vecLapl"] = std::move(vl);
+  }
+  names = {"gradPsi"}; if (mag) names.push_back("mu"); opt(names, "dmA"); names.push_back("divB");
+  chain(names, "scaLaplPos");
+  for (const char* nm : {"curlCurl", "gradDiv", "vecLapl"}) ops[nm] = dev_download<S>(dev.at(nm)->h);
+  {
+    mx::Csr<S> sl = dev_download<S>(dev.at("scaLaplPos")->h);
+    for (auto& v : sl.val) v = v * S(-1.0);                     // scaleInPlace(sl, -1)
+    ops["scaLapl"] = std::move(sl);
+  }
+  if (pec && mag) { chain({"mu", "dmA"}, "mRhs"); ops["mRhs"] = dev_download<S>(dev.at("mRhs")->h); }
+  else if (pec) ops["mRhs"] = ops.at("dmA");
+  else if (mag) ops["mRhs"] = ops.at("mu");
+  else ops["mRhs"] = mx::diagonal<S>(mx::UVec<S>(a.bfield().gids.size(), S(1.0)));
+}
+template void mxh_device_chain<double>(mxg_ctx*, const mx::YeeAssembler<double>&, std::map<std::string, mx::Csr<double> >&);
+template void mxh_device_chain<std::complex<double> >(mxg_ctx*, const mx::YeeAssembler<std::complex<double> >&,
+                                                      std::map<std::string, mx::Csr<std::complex<double> > >&);
 
 extern "C" int mxh_sim_device_chain(mxg_ctx* ctx, mxh_sim* s) {
   try {
@@ -267,60 +332,7 @@ extern "C" int mxh_sim_device_chain(mxg_ctx* ctx, mxh_sim* s) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     if (s->chain_ready) return 0;
-    const mx::YeeAssembler<double>& a = *s->asmb;
-    const bool pec = a.hasPec(), diel = a.hasDielectric(), mag = a.hasMu();
-    std::map<std::string, std::unique_ptr<DevMat> > dev;
-    auto get = [&](const std::string& nm) -> mxg_csr* {            // upload a single operator on first use
-      auto it = dev.find(nm);
-      if (it == dev.end()) {
-        const mx::Csr<double>& m = s->ops.at(nm);
-        std::unique_ptr<DevMat> d(new DevMat());
-        dev_check(mxg_csr_create(ctx, m.nrows, m.ncols, 0, m.rowptr.data(), m.col.data(), m.val.data(), 0, nullptr, &d->h), "mxg_csr_create");
-        it = dev.emplace(nm, std::move(d)).first;
-      }
-      return it->second->h;
-    };
-    auto chain = [&](const std::vector<std::string>& names, const std::string& out) {   // massiveCrsMultiply, src/MxUtil.cpp:318-371
-      std::unique_ptr<DevMat> res;
-      const mxg_csr* cur = get(names[0]);
-      for (size_t i = 1; i < names.size(); ++i) {
-        std::unique_ptr<DevMat> nx(new DevMat());
-        dev_check(mxg_csr_multiply(ctx, get(names[i]), cur, &nx->h), "mxg_csr_multiply");
-        res = std::move(nx);
-        cur = res->h;
-      }
-      if (!res) throw std::runtime_error("mxh_sim_device_chain: a chain needs two factors");
-      dev[out] = std::move(res);
-    };
-    auto opt = [&](std::vector<std::string>& v, const char* nm) { if (pec) v.push_back(nm); };
-    std::vector<std::string> names;
-    names = {"curlB"}; if (diel) names.push_back("invEps"); opt(names, "dmL"); names.push_back("curlE");
-    chain(names, "curlCurl");
-    names.clear(); if (mag) names.push_back("mu"); opt(names, "dmA"); names.push_back("divB"); opt(names, "dmVInv");
-    if (mag) names.push_back("invMuVolAve");
-    if (diel) names.push_back("invEpsVolAve");
-    if (mag) names.push_back("invMuVolAve");
-    names.push_back("gradPsi"); if (mag) names.push_back("mu"); opt(names, "dmA");
-    chain(names, "gradDiv");
-    {
-      DevMat sum;
-      dev_check(mxg_csr_add(ctx, dev.at("curlCurl")->h, 1.0, dev.at("gradDiv")->h, -1.0, &sum.h), "mxg_csr_add");
-      std::unique_ptr<DevMat> vl(new DevMat());
-      dev_check(mxg_csr_purge(ctx, sum.h, 1.0e-12, &vl->h), "mxg_csr_purge");
-      dev["vecLapl"] = std::move(vl);
-    }
-    names = {"gradPsi"}; if (mag) names.push_back("mu"); opt(names, "dmA"); names.push_back("divB");
-    chain(names, "scaLaplPos");
-    for (const char* nm : {"curlCurl", "gradDiv", "vecLapl"}) s->ops[nm] = dev_download(dev.at(nm)->h);
-    {
-      mx::Csr<double> sl = dev_download(dev.at("scaLaplPos")->h);
-      for (auto& v : sl.val) v = v * -1.0;                        // scaleInPlace(sl, -1)
-      s->ops["scaLapl"] = std::move(sl);
-    }
-    if (pec && mag) { chain({"mu", "dmA"}, "mRhs"); s->ops["mRhs"] = dev_download(dev.at("mRhs")->h); }
-    else if (pec) s->ops["mRhs"] = s->ops.at("dmA");
-    else if (mag) s->ops["mRhs"] = s->ops.at("mu");
-    else s->ops["mRhs"] = mx::diagonal<double>(mx::UVec<double>(a.bfield().gids.size(), 1.0));
+    mxh_device_chain<double>(ctx, *s->asmb, s->ops);
     s->chain_ready = true;
     return 0;
   } catch (const std::exception& e) {

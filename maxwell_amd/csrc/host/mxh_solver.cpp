@@ -36,7 +36,12 @@ void mxh_solver_build_complex(mxh_solver& s, mxg_ctx* ctx, mx::YeeConfig const& 
     int pg[3];
     if (mxh_partition(box.n, s.comm->numProc(), s.comm->myPID(), pg, box.boxLo, box.boxHi) != 0) throw std::runtime_error(mxh_last_error());
     s.boxAsmC = std::make_shared<mx::YeeAssembler<MxComplex> >(box);
-    s.boxOpsC = s.boxAsmC->waveOps();
+    // the window chain on this rank's GPU (MXH_DEVICE_CHAIN=0: on the host), like the real boxes
+    {
+      const char* dc = getenv("MXH_DEVICE_CHAIN");
+      if (dc && atoi(dc) == 0) s.boxOpsC = s.boxAsmC->waveOps();
+      else { s.boxOpsC = s.boxAsmC->singleOps(); mxh_device_chain<MxComplex>(ctx, *s.boxAsmC, s.boxOpsC); }
+    }
     s.sim = rcp(new MxEMSim<3>(box, s.comm, pl, nullptr, s.boxAsmC));
     s.sim->setPrebuiltOps(&s.boxOpsC);
   } else {
