@@ -203,6 +203,7 @@ def main():
     t0 = time.perf_counter()
     if world == 1 and not args.dist_selftest:
         sim = mx.Sim.pillbox(args.n)
+        sim.form_chain_on_device(ctx)          # the operator chain on the GPU (row f2), bit-identical to the host chain
         A = sim.to_device(ctx, "vecLapl", shift=shift)
         workload = "pillbox %d^3 Yee cells, vecLapl - shift*dmA (example/pillbox.py geometry)" % args.n
         parallelism = "1 GPU"
@@ -335,6 +336,15 @@ def main():
                         tk = hbm_summary[0]["kernels"]["k_spmv_tile"]
                         out[key]["traffic"] = int(tk["total"])
                         out[key]["traffic_source"] = hbm_summary[1] + " (FETCH_SIZE x2 + WRITE_SIZE)"
+                    try:
+                        # what a pure stream with the same read / write mix reaches on this device in this run
+                        wb = Ac.nrows * 8 * args.k
+                        tms = ctx.stream_ceiling_ms(moved - wb, wb, 20)
+                        out[key]["stream_ceiling"] = {"ms": round(tms, 5), "GBps": round(moved / (tms * 1e-3) / 1e9, 1),
+                                                      "kernel_frac_of_ceiling": round(tms / cms, 4),
+                                                      "what": "mxg_bench_stream on bytes_moved_per_launch: %d read, %d written" % (moved - wb, wb)}
+                    except Exception as e:
+                        out[key]["stream_ceiling"] = {"error": str(e)}
                     if args.spmm_k > 1 and args.k == 1:
                         # block of vectors through the tile form: the pattern is loaded once for all columns of a pass
                         kk = args.spmm_k

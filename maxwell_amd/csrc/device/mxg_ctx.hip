@@ -103,17 +103,23 @@ int mxg_vec_alloc(mxg_ctx* c, size_t bytes, void** out) {
 
 void mxg_vec_release(mxg_ctx* c, void* p, size_t bytes) {
   static const bool off = getenv("MXG_VEC_CACHE") && atoi(getenv("MXG_VEC_CACHE")) == 0;   // experiments
+  std::vector<void*> drop;                    // the newest buffers stay: the oldest make room (another phase's sizes)
   {
     std::lock_guard<std::mutex> lock(c->vec_cache_mutex);
-    if (!off && bytes <= VEC_CACHE_MAX_ONE && c->vec_cache.size() < VEC_CACHE_MAX_COUNT &&
-        c->vec_cache_bytes + bytes <= VEC_CACHE_MAX_BYTES) {
+    if (off || bytes > VEC_CACHE_MAX_ONE) drop.push_back(p);
+    else {
       c->vec_cache.emplace_back(bytes, p);
       c->vec_cache_bytes += bytes;
-      return;
+      while (c->vec_cache.size() > VEC_CACHE_MAX_COUNT || c->vec_cache_bytes > VEC_CACHE_MAX_BYTES) {
+        drop.push_back(c->vec_cache.front().second);
+        c->vec_cache_bytes -= c->vec_cache.front().first;
+        c->vec_cache.erase(c->vec_cache.begin());
+      }
     }
   }
+  if (drop.empty()) return;
   hipStreamSynchronize(c->stream);
-  hipFree(p);
+  for (void* q : drop) hipFree(q);
 }
 
 void mxg_vec_cache_flush(mxg_ctx* c) {

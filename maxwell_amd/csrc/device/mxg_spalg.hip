@@ -65,14 +65,14 @@ __global__ __launch_bounds__(SA_BLOCK) void k_scan_fix(long long* __restrict__ o
 
 int exclusive_scan(mxg_ctx* c, const long long* d_in, long long n, long long* d_out /* n + 1 */) {
   const long long nb = std::max<long long>((n + SA_BLOCK - 1) / SA_BLOCK, 1);
-  long long* bsum = nullptr;
-  MXG_HIP(hipMalloc(&bsum, sizeof(long long) * nb));
+  struct Buf { long long* p = nullptr; ~Buf() { if (p) hipFree(p); } } hold;   // freed on every exit path
+  MXG_HIP(hipMalloc(&hold.p, sizeof(long long) * nb));
+  long long* bsum = hold.p;
   hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SA_BLOCK), 0, c->stream, d_in, n, d_out, bsum);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, c->stream, bsum, nb);
   hipLaunchKernelGGL(k_scan_fix, dim3((unsigned)nb), dim3(SA_BLOCK), 0, c->stream, d_out, n, (const long long*)bsum);
   MXG_HIP(hipGetLastError());
   MXG_HIP(hipStreamSynchronize(c->stream));
-  hipFree(bsum);
   return 0;
 }
 
