@@ -116,6 +116,9 @@ int mxh_mg_create(mxg_ctx* ctx, mxh_sim* sim, const char* op, double shift, int6
 int mxh_mg_destroy(mxh_mg* mg);
 mxg_mg* mxh_mg_handle(mxh_mg* mg);          /* the device V-cycle (for mxg_solve_opts.mg) */
 mxg_csr* mxh_mg_fine_matrix(mxh_mg* mg);    /* level-0 operator on the device */
+/* a matrix of the hierarchy, borrowed (tests): which = 'A' the operator of level l, 'P' the prolongation from level l + 1
+ * to level l, 'R' the restriction from level l to level l + 1; NULL when there is none */
+mxg_csr* mxh_mg_level_matrix(mxh_mg* mg, int level, char which);
 int mxh_mg_level_sizes(mxh_mg* mg, int64_t* rows, int64_t* nnz, int* nlevels);   /* arrays of >= 16 */
 
 /* ---------------------------------------------------------------------------------------

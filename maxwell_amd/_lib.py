@@ -144,6 +144,7 @@ MXH_SIGNATURES = {
     "mxh_mg_destroy": (C.c_int, [vp]),
     "mxh_mg_handle": (vp, [vp]),
     "mxh_mg_fine_matrix": (vp, [vp]),
+    "mxh_mg_level_matrix": (vp, [vp, C.c_int, C.c_char]),
     "mxh_mg_level_sizes": (C.c_int, [vp, c_i64p, c_i64p, c_ip]),
     "mxh_solver_default_params": (None, [C.POINTER(SolverParamsC)]),
     "mxh_solver_create": (C.c_int, [vp, vp, C.POINTER(SolverParamsC), C.POINTER(vp)]),

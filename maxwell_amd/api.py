@@ -519,6 +519,17 @@ class Multigrid:
         m._owner = self
         return m
 
+    def level_matrix(self, level, which="A"):
+        """Borrowed wrapper of a matrix of the hierarchy: 'A' level operator, 'P' prolongation level + 1 -> level,
+        'R' restriction level -> level + 1 (tests)."""
+        h = self.lib.mxh_mg_level_matrix(self.h, int(level), which.encode())
+        if not h:
+            raise MxError("Multigrid.level_matrix: no matrix %s at level %d" % (which, level))
+        m = CsrMatrix._wrap(self.ctx, C.c_void_p(h))
+        m.close = lambda: None
+        m._owner = self
+        return m
+
     def apply(self, r, z):
         _chk(self.ctx.lib.mxg_mg_apply(self.ctx.h, self.handle, r.h, z.h), self.ctx.lib)
 

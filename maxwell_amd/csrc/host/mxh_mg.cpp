@@ -96,6 +96,12 @@ extern "C" int mxh_mg_create(mxg_ctx* ctx, mxh_sim* sim, const char* op, double 
 extern "C" int mxh_mg_destroy(mxh_mg* mg) { delete mg; return 0; }
 extern "C" mxg_mg* mxh_mg_handle(mxh_mg* mg) { return mg->mg; }
 extern "C" mxg_csr* mxh_mg_fine_matrix(mxh_mg* mg) { return mg->A[0]; }
+extern "C" mxg_csr* mxh_mg_level_matrix(mxh_mg* mg, int level, char which) {
+  if (!mg || level < 0) return nullptr;
+  const std::vector<mxg_csr*>& v = which == 'A' ? mg->A : (which == 'P' ? mg->P : mg->R);
+  if (which != 'A' && which != 'P' && which != 'R') return nullptr;
+  return (size_t)level < v.size() ? v[(size_t)level] : nullptr;
+}
 extern "C" int mxh_mg_level_sizes(mxh_mg* mg, int64_t* rows, int64_t* nnz, int* nlevels) {
   const int n = (int)std::min<size_t>(mg->rows.size(), 16);
   for (int i = 0; i < n; ++i) { if (rows) rows[i] = mg->rows[i]; if (nnz) nnz[i] = mg->nnz[i]; }

@@ -114,3 +114,32 @@ def test_multigrid_preconditioner(ctx, rng, smoother):
         assert np.linalg.norm(host @ xm.to_numpy()[:, 0] - rhs) <= 2e-9
         if op == "shifted":   # non-singular: both solves agree
             assert np.linalg.norm(xm.to_numpy() - xj.to_numpy()) <= 1e-7 * np.linalg.norm(xj.to_numpy())
+
+
+def test_multigrid_hierarchy_is_galerkin(ctx):
+    """The hierarchy builder (mx_mg.hpp: 2x2x2 aggregates per component, one-pass Galerkin product with merge insertion)
+    against scipy on the matrices it uploads: P has one unit entry per row with a non-zero diagonal, R = P^T, every
+    coarse operator equals R A P on the same pattern (entries summed in another order: to rounding)."""
+    import scipy.sparse as sp
+    sim = mx.Sim.pillbox(24)
+    shift = yee.default_shift([1, 1, 1])
+    for op in ("shifted", "scaLapl"):
+        mg = mx.Multigrid(ctx, sim, op, shift, min_coarse=200)
+        nl = len(mg.levels)
+        assert nl >= 3
+        for l in range(nl - 1):
+            A, P, R = (mg.level_matrix(l, w).to_scipy() for w in "APR")
+            Ac = mg.level_matrix(l + 1, "A").to_scipy()
+            assert (A.shape[0], A.nnz) == tuple(mg.levels[l]) and (Ac.shape[0], Ac.nnz) == tuple(mg.levels[l + 1])
+            active = A.diagonal() != 0.0
+            assert np.array_equal(np.diff(P.indptr), active.astype(np.int64)) and np.all(P.data == 1.0)
+            assert (R - P.T).nnz == 0
+            want = (R @ A @ P).tocsr(); want.sort_indices()
+            got = Ac.tocsr(); got.sort_indices()
+            assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+            d = got - want
+            scale = np.abs(want.data).max()
+            assert d.nnz == 0 or np.abs(d.data).max() <= 1e-13 * scale, (op, l)
+            assert all(np.all(np.diff(got.indices[got.indptr[i]:got.indptr[i + 1]]) > 0) for i in range(0, got.shape[0], 97))   # sorted, unique
+        with pytest.raises(mx.MxError):
+            mg.level_matrix(nl, "A")
