@@ -768,13 +768,29 @@ extern "C" int mxg_csr_create(mxg_ctx* c, int64_t nrows, int64_t ncols_owned, in
   MXG_CHECK(nghost == 0 || plan != nullptr, "mxg_csr_create: ghosts without a halo plan");
   const int64_t nnz = rowptr[nrows];
   const int64_t ncols = ncols_owned + nghost;
-  for (int64_t r = 0; r < nrows; ++r)
-    MXG_CHECK(rowptr[r + 1] >= rowptr[r], "mxg_csr_create: rowptr not monotone at row %lld",
-              (long long)r);
-  for (int64_t q = 0; q < nnz; ++q)
-    MXG_CHECK(colidx[q] >= 0 && colidx[q] < ncols,
-              "mxg_csr_create: column index %d out of range [0,%lld) at entry %lld", colidx[q],
-              (long long)ncols, (long long)q);
+  {
+    // validation on host threads (a serial pass over the 1.5e8 entries of a 256^3 operator cost 0.1 s per matrix);
+    // the first offending row / entry in index order is the one reported
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (const char* e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) nthreads = (unsigned)v; }
+    if (nthreads > 32) nthreads = 32;
+    if (nthreads < 1 || nnz < (int64_t)1 << 20) nthreads = 1;
+    std::vector<int64_t> bad_row(nthreads, -1), bad_ent(nthreads, -1);
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i < nthreads; ++i)
+      pool.emplace_back([&, i] {
+        for (int64_t r = nrows * i / nthreads; r < nrows * (i + 1) / nthreads; ++r)
+          if (rowptr[r + 1] < rowptr[r]) { bad_row[i] = r; break; }
+        for (int64_t q = nnz * i / nthreads; q < nnz * (i + 1) / nthreads; ++q)
+          if (colidx[q] < 0 || colidx[q] >= ncols) { bad_ent[i] = q; break; }
+      });
+    for (auto& th : pool) th.join();
+    for (unsigned i = 0; i < nthreads; ++i)
+      MXG_CHECK(bad_row[i] < 0, "mxg_csr_create: rowptr not monotone at row %lld", (long long)bad_row[i]);
+    for (unsigned i = 0; i < nthreads; ++i)
+      MXG_CHECK(bad_ent[i] < 0, "mxg_csr_create: column index %d out of range [0,%lld) at entry %lld", colidx[bad_ent[i]],
+                (long long)ncols, (long long)bad_ent[i]);
+  }
   MXG_HIP(hipSetDevice(c->device));
   mxg_csr* a = new mxg_csr();
   a->ctx = c;

@@ -191,3 +191,27 @@ def test_anasazi_multivec_traits_invariants(ctx, rng):
     Z.set_block(B.view([1]), [0]); z = Z.to_numpy(); assert np.array_equal(z[:, 0], b[:, 1])
     # MvScale
     Z.scale(0.0); assert np.all(Z.norm2() == 0)
+
+
+def test_vector_storage_is_recycled_clean(ctx, rng):
+    """Vector storage comes back from the context's cache (mxg_vec_alloc / release, mxg_ctx.hip): a new vector is zero
+    whatever its storage held before, live vectors never share storage, and more released buffers than the cache keeps
+    (32) are evicted oldest first without disturbing anybody."""
+    sizes = [1000, 4096, 77777]
+    live = []
+    for rep in range(3):
+        batch = []
+        for i in range(45):                     # > the cache's buffer count
+            n = sizes[i % 3] + (i // 3 if rep == 1 else 0)     # second round: many distinct sizes (forces eviction)
+            v = mx.MultiVec(ctx, n, 2, is_complex=(i % 2 == 1))
+            assert not np.any(v.to_numpy()), (rep, i)
+            v.fill(float(rep * 100 + i + 1))
+            batch.append((v, float(rep * 100 + i + 1)))
+        for v, val in batch:                    # nobody wrote into anybody else's storage
+            assert np.all(v.to_numpy() == val)
+        for v, _ in batch[5:]:
+            v.close()
+        live.extend(batch[:5])
+    for v, val in live:
+        assert np.all(v.to_numpy() == val)
+        v.close()
