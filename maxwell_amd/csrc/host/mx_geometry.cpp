@@ -38,9 +38,16 @@ Mat3 inverse(const Mat3& m) {
 
 Shape::Shape() : sign_(1.0), A_(Mat3::eye()), Ainv_(Mat3::eye()) {}
 
+void Shape::refreshPlain() {
+  bool id = Ainvb_[0] == 0.0 && Ainvb_[1] == 0.0 && Ainvb_[2] == 0.0;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) id = id && Ainv_.a[i][j] == (i == j ? 1.0 : 0.0);
+  plain_ = id;
+}
+
 void Shape::translate(const Vec3& v) {  // src/MxShape.cpp:183-189
   b_ = b_ + v;
   Ainvb_ = Ainv_.mul(b_);
+  refreshPlain();
 }
 
 void Shape::rotate(const Vec3& axis, double angle, const Vec3& pivot) {  // src/MxShape.cpp:98-127
@@ -60,6 +67,7 @@ void Shape::rotate(const Vec3& axis, double angle, const Vec3& pivot) {  // src/
   b_ = R.mul(b_ - pivot) + pivot;
   Ainv_ = inverse(A_);
   Ainvb_ = Ainv_.mul(b_);
+  refreshPlain();
 }
 
 void Shape::scale(const Vec3& mags, const Vec3& origin) {  // src/MxShape.cpp:163-172
@@ -69,6 +77,7 @@ void Shape::scale(const Vec3& mags, const Vec3& origin) {  // src/MxShape.cpp:16
   b_ = S.mul(b_ - origin) + origin;
   Ainv_ = inverse(A_);
   Ainvb_ = Ainv_.mul(b_);
+  refreshPlain();
 }
 
 void Shape::reflect(const Vec3& normal, const Vec3& p) {  // src/MxShape.cpp:200-216
@@ -80,6 +89,7 @@ void Shape::reflect(const Vec3& normal, const Vec3& p) {  // src/MxShape.cpp:200
   b_ = M.mul(b_ - p) + p;
   Ainv_ = inverse(A_);
   Ainvb_ = Ainv_.mul(b_);
+  refreshPlain();
 }
 
 HalfSpace::HalfSpace(const Vec3& point, const Vec3& normal) {

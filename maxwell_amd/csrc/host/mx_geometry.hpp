@@ -61,7 +61,10 @@ class Shape {
  public:
   Shape();
   virtual ~Shape() {}
-  double func(const Vec3& p) const { return sign_ * localFunc(Ainv_.mul(p) - Ainvb_); }
+  // An untransformed shape (Ainv = I, Ainv b = 0 exactly: every node of a CSG tree the deck does not move) skips the
+  // mat-vec: I p - 0 is p to the bit for every p (+-0 apart, which no local function tells apart) - the fractions of a
+  // 256^3 lattice evaluate func 4.4e8 times.
+  double func(const Vec3& p) const { return sign_ * (plain_ ? localFunc(p) : localFunc(Ainv_.mul(p) - Ainvb_)); }
   Vec3 gradFunc(const Vec3& p) const { return sign_ * Ainv_.lmul(localGrad(Ainv_.mul(p) - Ainvb_)); }
   void translate(const Vec3& v);
   void rotate(const Vec3& axis, double angle, const Vec3& pivot);
@@ -77,9 +80,11 @@ class Shape {
   virtual Vec3 localGrad(const Vec3& q) const = 0;
 
  private:
+  void refreshPlain();
   double sign_;
   Mat3 A_, Ainv_;
   Vec3 b_, Ainvb_;
+  bool plain_ = true;
 };
 
 class HalfSpace : public Shape {
