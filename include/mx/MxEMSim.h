@@ -26,7 +26,7 @@ class MxGridField {
  public:
   MxGridField(std::string name, RCP<MxMap> map, std::vector<double> mask, int numComps = 3,
               std::string fieldName = "", const int* res = nullptr)
-      : mName(name), mMap(map), mMask(mask), mNumComps(numComps), mFieldName(fieldName) {
+      : mName(name), mMap(map), mMask(std::move(mask)), mNumComps(numComps), mFieldName(fieldName) {
     for (int i = 0; i < 3; ++i) mRes[i] = res ? res[i] : 0;
   }
   std::string getName() const { return mName; }
@@ -145,7 +145,7 @@ class MxEMSim {
     RCP<MxMap> map;
     if (!mWindowed) {
       g.assign(f.gids.begin(), f.gids.end());
-      map = rcp(new MxMap(g, comm));
+      map = rcp(new MxMap(std::move(g), comm));
     } else {
       // owned entries only (ascending global id); ghosts are a matter of each operator (MxCrsMatrix)
       std::vector<double> m2;
@@ -154,7 +154,7 @@ class MxEMSim {
       mask.swap(m2);
       double total = (double)g.size();
       MX_ABI(mxg_comm_allreduce_host(comm->getCtx(), &total, 1), "MxEMSim (global map size)");
-      map = rcp(new MxMap((size_t)(total + 0.5), g, comm));
+      map = rcp(new MxMap((size_t)(total + 0.5), std::move(g), comm));
       const int ncomp = f.ncomp;
       const int n[3] = {mCfg.n[0], mCfg.n[1], mCfg.n[2]}, pg[3] = {mProcGrid[0], mProcGrid[1], mProcGrid[2]};
       map->setOwnerFunction([ncomp, n, pg](MxIndex gid) {
@@ -165,7 +165,7 @@ class MxEMSim {
     }
     const std::string nm(name);
     const char* cls = nm == "bfield" ? "YeeFitBField" : (nm == "efield" ? "YeeFitEField" : "YeeFitPsiField");
-    mFields[name] = std::make_shared<MxGridField<DIM> >(name, map, mask, f.ncomp, cls, mCfg.n);
+    mFields[name] = std::make_shared<MxGridField<DIM> >(name, map, std::move(mask), f.ncomp, cls, mCfg.n);
   }
   mx::YeeConfig mCfg;
   MxGrid<DIM> mGrid;

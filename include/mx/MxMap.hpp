@@ -19,6 +19,11 @@ class MxMap {
   // arbitrary local index list; numGlobal = sum over ranks (serial: the local count)
   MxMap(const std::vector<MxIndex>& globalIndices, RCP<MxComm> comm)
       : gids_(globalIndices), comm_(comm), numGlobal_(globalIndices.size()) { buildLookup(); }
+  // the same, taking the list over (the 2e7-entry maps of a 256^3 problem are not copied)
+  MxMap(std::vector<MxIndex>&& globalIndices, RCP<MxComm> comm)
+      : gids_(std::move(globalIndices)), comm_(comm), numGlobal_(gids_.size()) { buildLookup(); }
+  MxMap(size_t numGlobal, std::vector<MxIndex>&& globalIndices, RCP<MxComm> comm)
+      : gids_(std::move(globalIndices)), comm_(comm), numGlobal_(numGlobal) { buildLookup(); }
   MxMap(size_t numGlobal, const std::vector<MxIndex>& globalIndices, RCP<MxComm> comm)
       : gids_(globalIndices), comm_(comm), numGlobal_(numGlobal) { buildLookup(); }
 

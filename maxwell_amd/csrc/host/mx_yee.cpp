@@ -1197,6 +1197,7 @@ Csr<S> YeeAssembler<S>::invEpsVolAve() const {
 template <typename S>
 std::vector<double> YeeAssembler<S>::usedMask() const {
   std::vector<double> m(B_.gids.size());
+#pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < (int64_t)B_.gids.size(); ++r) {
     int ucell[3], cell[3];
     winCell(B_.wcell[r], ucell);

@@ -1,4 +1,6 @@
 // C ABI over the eigen-driver (include/mxh.h, mxh_solver_*): MxSolver + MxMagWaveOp.
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 
@@ -22,9 +24,15 @@ void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::Parame
   // sim leaves it to MxMagWaveOp, which never reads the products back)
   if (sim->asmb->isWindowed() && !sim->chain_ready && mxh_sim_device_chain(ctx, sim) != 0)
     throw std::runtime_error(mxh_last_error());
+  const bool timing = getenv("MXH_VERBOSE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   s.sim = rcp(new MxEMSim<3>(sim->cfg, s.comm, pl, sim->asmb));
   s.sim->setPrebuiltOps(&sim->ops);     // single operators, or the whole chain when it has been formed
+  const auto t1 = std::chrono::steady_clock::now();
   s.solver.reset(new MxSolver<3, double>(s.sim, pl));
+  if (timing)
+    fprintf(stderr, "[mxh_solver] MxEMSim (grid, fields, maps) %.3f s, MxSolver (operator, preconditioner, eigenproblem) %.3f s\n",
+            std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
 }
 
 void mxh_solver_build_complex(mxh_solver& s, mxg_ctx* ctx, mx::YeeConfig const& cfg, Teuchos::ParameterList const& pl) {
