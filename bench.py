@@ -421,17 +421,31 @@ def main():
 
 def eigen_bench(mx, ctx, n):
     """eigenpairs/s = converged pairs / wall time of MxSolver::solve() (src/MxSolver.cpp:102-113)."""
+    def rss_gib():
+        try:
+            for line in open("/proc/self/status"):
+                if line.startswith("VmRSS:"):
+                    return int(line.split()[1]) / 2.0 ** 20
+        except OSError:
+            pass
+        return float("nan")
+    import resource
+    peak = lambda: resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2.0 ** 20
+    r0 = rss_gib()
     t0 = time.perf_counter()
     sim = mx.Sim.pillbox(n)
     t1 = time.perf_counter()
+    r1 = rss_gib(); p1 = peak()
     params = mx.SolverParams(nev=5, basis=30, tol=1e-8, shift=0.05 * (2.0 * np.pi) ** 2,
                              lin_type="cg", lin_tol=1e-9, prec_type="amg")
     solver = mx.Solver(ctx, sim, params)
     t2 = time.perf_counter()
+    r2 = rss_gib(); p2 = peak()
     nconv = solver.solve()
     t3 = time.perf_counter()
     log("eigen %d^3: assembly %.1f s, solver setup (operator chain, upload, stream encoding, multigrid) %.1f s, "
-        "MxSolver::solve() %.1f s (eigen-solve + residual / divergence checks + E fields)" % (n, t1 - t0, t2 - t1, t3 - t2))
+        "MxSolver::solve() %.1f s (eigen-solve + residual / divergence checks + E fields); host RSS %.1f GiB before, "
+        "%.1f after assembly (peak so far %.1f), %.1f after solver setup (peak %.1f)" % (n, t1 - t0, t2 - t1, t3 - t2, r0, r1, p1, r2, p2))
     st = solver.stats()
     res = [solver.result(i) for i in range(nconv)]
     return {"workload": "pillbox %d^3, nev 5, tol 1e-8, block Krylov-Schur shift-invert, multigrid-preconditioned CG inner solves (tol 1e-9; V(2,2), Chebyshev smoother)" % n,

@@ -220,6 +220,11 @@ class MxCrsMatrix {
   // host-side CSR (setup algebra, tests) and device handle (advanced usage)
   mx::Csr<Scalar> const& getHostCsr() const { return host(); }
   mxg_csr* getRawMatrix() const { ensureDevice(); return mDev; }
+  // give the host copy back once the device holds the matrix (it returns on demand: host()); the 256^3 shifted operator
+  // is 2.2 GB that nothing reads again after the multigrid setup
+  void releaseHostCopy() const {
+    if (mDev && mHostValid && !mBorrow) { mHost = mx::Csr<Scalar>(); mHostValid = false; }
+  }
   // never re-encode this matrix (operators outside the inner loops whose encoding pass would cost more than it saves)
   void keepPlain() const { mNoCompress = true; }
   // the setup-time products / sums of single-rank matrices (real or complex) run on the GPU (MXH_DEVICE_CHAIN=0: on the host)

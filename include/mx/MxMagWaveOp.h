@@ -441,9 +441,12 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     // (level 0 of each hierarchy is the operator's own device matrix: no second copy of the 2.2 GB 256^3 operator)
     mVecMg = mxh_mg_build(ctx, mVecMgMatrix->getHostCsr(), a.bfield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9,
                           mVecMgMatrix->getRawMatrix());
-    if (mHasCurlNull && !mScaMg)
+    mVecMgMatrix->releaseHostCopy();
+    if (mHasCurlNull && !mScaMg) {
       mScaMg = mxh_mg_build(ctx, mScaMgMatrix->getHostCsr(), a.psifield(), a.config().n, 2000, levels, sweeps, 30, 0.85, 1.9,
                             mScaMgMatrix->getRawMatrix());
+      mScaMgMatrix->releaseHostCopy();
+    }
   }
 
   mxg_mg* vecMgHandle() const { return mVecDmg ? mVecDmg->handle() : (mVecMg ? mxh_mg_handle(mVecMg) : nullptr); }
