@@ -128,6 +128,15 @@ __global__ void k_cg_dir(long long n, double* __restrict__ p, const double* __re
 }
 
 
+// x += a p alone (a converged multigrid-CG solve leaves before the direction kernel)
+__global__ void k_cg_xstep(long long n, const double* __restrict__ p, double* __restrict__ x,
+                           const double* __restrict__ scal, int irz) {
+  const double pq = scal[S_PQ];
+  const double alpha = pq != 0.0 ? scal[irz] / pq : 0.0;
+  const long long stride = (long long)gridDim.x * CGB;
+  for (long long i = (long long)blockIdx.x * CGB + threadIdx.x; i < n; i += stride) x[i] += alpha * p[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // Aggregation multigrid V-cycle (K11 replacement, SpMV-only): every ingredient is a CSR product
 // (level operator, prolongation, restriction) or a fused vector kernel.
@@ -642,6 +651,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
   mxg_mv* zc = z;                        // where the preconditioned residual sits (multigrid: its own level-0 vector)
   // z = V-cycle(r) (in the hierarchy's own vector: -4.6 % at 256^3 against two copies) and r.z into slot `slot`
   auto mgprecond = [&](int slot) -> int { return mg_apply_nocopy(c, o->mg, r, &zc, scal + slot); };
+  static const double near_factor = getenv("MXG_CG_NEAR") ? atof(getenv("MXG_CG_NEAR")) : 10.0;   // experiments: 0 = never test early
   while (res > o->tol && it < max_iters) {
     if (mgprec) MXG_TRY(mgprecond(S_RZ0));
     else MXG_TRY(apply_prec(c, A, o, r, z));
@@ -650,7 +660,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
     MXG_TRY(allreduce(scal + S_RZ0, 1));
     int cur = S_RZ0;
     double rnorm = res;
-    bool stalled = false;
+    bool stalled = false, synced = false;
     while (rnorm > o->tol && it < max_iters) {
       const int todo = std::min(CHUNK, max_iters - it);
       for (int s = 0; s < todo; ++s) {
@@ -671,7 +681,22 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
           // while this cycle still runs (a stream synchronisation per iteration left the GPU idle ~90 us each)
           if (mxg_comm_on(c)) MXG_TRY(allreduce(scal + S_RR, 1));
           MXG_HIP(hipMemcpyAsync(c->h_result, scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
-          MXG_HIP(hipEventRecord(c->ev_scal, c->stream));
+          // ... except close to the tolerance (the last one or two iterations of a solve): there the test is made
+          // at once, and a converged solve does not run the cycle, the dot and the direction it would throw away
+          // (1.2 ms of a 256^3 vector solve; the synchronisation costs 0.09)
+          synced = rnorm <= o->tol * near_factor;
+          if (synced) {
+            MXG_HIP(hipStreamSynchronize(c->stream));
+            const double rr = c->h_result[S_RR];
+            if (rr == rr && c->h_result[S_PQ] != 0.0 && sqrt(rr) <= o->tol) {
+              hipLaunchKernelGGL(k_cg_xstep, dim3(grid), dim3(CGB), 0, c->stream, n, (const double*)p->colptr(0), x->colptr(0),
+                                 (const double*)scal, cur);     // x += a p: the part of k_cg_dir that is still owed
+              if (first) o->mg->first_done = false;             // the cycle that would have consumed it is not run
+              break;
+            }
+          } else {
+            MXG_HIP(hipEventRecord(c->ev_scal, c->stream));
+          }
           // z = V-cycle(r), r.z replaces the placeholder the update kernel left in slot nxt
           MXG_TRY(mgprecond(nxt));
           if (mxg_comm_on(c)) MXG_TRY(allreduce(scal + nxt, 1));
@@ -685,7 +710,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
       MXG_HIP(hipGetLastError());
       it += todo;
       if (mgprec) {
-        MXG_HIP(hipEventSynchronize(c->ev_scal));
+        if (!synced) MXG_HIP(hipEventSynchronize(c->ev_scal));
       } else {
         MXG_HIP(hipMemcpyAsync(c->h_result, scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
         MXG_HIP(hipStreamSynchronize(c->stream));
