@@ -67,7 +67,8 @@ int apply_prec(mxg_ctx* c, const mxg_csr* A, const mxg_solve_opts* o, const mxg_
 constexpr int CGB = 256;
 enum { S_RZ0 = 0, S_RR = 1, S_RZ1 = 2, S_PQ = 3 };   // r.r sits between the two r.z slots: one all-reduce covers both
 
-__global__ void k_cg_update(long long n, double* __restrict__ r, const double* __restrict__ q,
+__global__ void k_cg_update(long long n, double* __restrict__ xu, const double* __restrict__ pu, double* __restrict__ r,
+                            const double* __restrict__ q,
                             double* __restrict__ z, const double* __restrict__ diag,
                             const double* __restrict__ scal, int irz, double* __restrict__ partial,
                             double* __restrict__ zmg, const double* __restrict__ dmg, double omg) {
@@ -77,6 +78,7 @@ __global__ void k_cg_update(long long n, double* __restrict__ r, const double* _
   double srz = 0.0, srr = 0.0;
   const long long stride = (long long)gridDim.x * CGB;
   for (long long i = (long long)blockIdx.x * CGB + threadIdx.x; i < n; i += stride) {
+    if (xu) xu[i] += alpha * pu[i];      // (x updated here instead of in k_cg_dir: MXG_CG_XMOVE=0)
     const double ri = r[i] - alpha * q[i];
     r[i] = ri;
     double zi = ri;
@@ -122,7 +124,7 @@ __global__ void k_cg_dir(long long n, double* __restrict__ p, const double* __re
   const long long stride = (long long)gridDim.x * CGB;
   for (long long i = (long long)blockIdx.x * CGB + threadIdx.x; i < n; i += stride) {
     const double po = p[i];
-    x[i] += alpha * po;
+    if (x) x[i] += alpha * po;
     p[i] = z[i] + beta * po;
   }
 }
@@ -651,6 +653,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
   mxg_mv* zc = z;                        // where the preconditioned residual sits (multigrid: its own level-0 vector)
   // z = V-cycle(r) (in the hierarchy's own vector: -4.6 % at 256^3 against two copies) and r.z into slot `slot`
   auto mgprecond = [&](int slot) -> int { return mg_apply_nocopy(c, o->mg, r, &zc, scal + slot); };
+  static const bool xmove = !(getenv("MXG_CG_XMOVE") && atoi(getenv("MXG_CG_XMOVE")) == 0);   // experiments: x += a p in k_cg_dir (1) or k_cg_update (0)
   static const double near_factor = getenv("MXG_CG_NEAR") ? atof(getenv("MXG_CG_NEAR")) : 10.0;   // experiments: 0 = never test early
   while (res > o->tol && it < max_iters) {
     if (mgprec) MXG_TRY(mgprecond(S_RZ0));
@@ -669,7 +672,8 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
         MXG_TRY(allreduce(scal + S_PQ, 1));
         double* zmg = nullptr; const double* dmg = nullptr; double omg = 0.0;
         const bool first = mgprec && mg_first_step(o->mg, &zmg, &dmg, &omg);
-        hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(CGB), 0, c->stream, n, r->colptr(0), (const double*)q->colptr(0),
+        hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(CGB), 0, c->stream, n, xmove ? (double*)nullptr : x->colptr(0),
+                           (const double*)p->colptr(0), r->colptr(0), (const double*)q->colptr(0),
                            mgprec ? (double*)nullptr : z->colptr(0), diag, (const double*)scal, cur, c->d_partial,
                            first ? zmg : (double*)nullptr, dmg, omg);
         if (first) o->mg->first_done = true;
@@ -689,8 +693,9 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
             MXG_HIP(hipStreamSynchronize(c->stream));
             const double rr = c->h_result[S_RR];
             if (rr == rr && c->h_result[S_PQ] != 0.0 && sqrt(rr) <= o->tol) {
-              hipLaunchKernelGGL(k_cg_xstep, dim3(grid), dim3(CGB), 0, c->stream, n, (const double*)p->colptr(0), x->colptr(0),
-                                 (const double*)scal, cur);     // x += a p: the part of k_cg_dir that is still owed
+              if (xmove)
+                hipLaunchKernelGGL(k_cg_xstep, dim3(grid), dim3(CGB), 0, c->stream, n, (const double*)p->colptr(0), x->colptr(0),
+                                   (const double*)scal, cur);   // x += a p: the part of k_cg_dir that is still owed
               if (first) o->mg->first_done = false;             // the cycle that would have consumed it is not run
               break;
             }
@@ -704,7 +709,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
           MXG_TRY(allreduce(scal + std::min(nxt, (int)S_RR), 2));   // r.z (slot nxt) and r.r, adjacent
         }
         hipLaunchKernelGGL(k_cg_dir, dim3(grid), dim3(CGB), 0, c->stream, n, p->colptr(0),
-                           (const double*)zc->colptr(0), x->colptr(0), (const double*)scal, cur, nxt);
+                           (const double*)zc->colptr(0), xmove ? x->colptr(0) : (double*)nullptr, (const double*)scal, cur, nxt);
         cur = nxt;
       }
       MXG_HIP(hipGetLastError());
