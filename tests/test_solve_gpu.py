@@ -143,3 +143,34 @@ def test_multigrid_hierarchy_is_galerkin(ctx):
             assert all(np.all(np.diff(got.indices[got.indptr[i]:got.indptr[i + 1]]) > 0) for i in range(0, got.shape[0], 97))   # sorted, unique
         with pytest.raises(mx.MxError):
             mg.level_matrix(nl, "A")
+
+
+def test_multigrid_cg_loop_switches_do_not_change_the_iterates(ctx):
+    """The round-3 rearrangements of the multigrid-CG loop (mxg_solve.hip: convergence test at once near the tolerance,
+    x += a p in the direction kernel, the next cycle's first smoother step written by the update kernel) move work
+    between kernels without changing one operation: with each of them switched off in a child process the solution is
+    the same bit for bit and so is the iteration count.  The fused r.z (another order of the partial sums) agrees to
+    rounding."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r); import numpy as np; import maxwell_amd as mx\n"
+            "from oracle import yee\n"
+            "ctx = mx.Ctx(0); sim = mx.Sim.pillbox(40); shift = yee.default_shift([1, 1, 1])\n"
+            "mg = mx.Multigrid(ctx, sim, 'shifted', shift, smoother='chebyshev'); A = mg.fine_matrix()\n"
+            "rng = np.random.default_rng(11); b = sim.op('mRhs') @ rng.uniform(-1, 1, A.nrows)\n"
+            "B = mx.MultiVec.from_numpy(ctx, b); X = mx.MultiVec(ctx, A.nrows, 1)\n"
+            "it, conv, res = A.solve(B, X, method='cg', tol=1e-9 * np.linalg.norm(b), precond='mg', mg=mg)\n"
+            "x = X.to_numpy()[:, 0]\n"
+            "print('RESULT ' + json.dumps(dict(it=it, conv=bool(conv), res=res, sha=hashlib.sha256(x.tobytes()).hexdigest(), nrm=float(np.linalg.norm(x)), x0=x[:64].tolist())))\n" % root)
+    outs = {}
+    for name, env in (("default", {}), ("near", {"MXG_CG_NEAR": "0"}), ("xmove", {"MXG_CG_XMOVE": "0"}),
+                      ("first", {"MXG_MG_FUSED_FIRST": "0"}), ("dot", {"MXG_MG_FUSED_DOT": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    d = outs["default"]
+    assert d["conv"] and 5 <= d["it"] <= 40
+    for name in ("near", "xmove", "first"):
+        assert outs[name]["it"] == d["it"] and outs[name]["sha"] == d["sha"], name
+    assert abs(outs["dot"]["it"] - d["it"]) <= 1 and outs["dot"]["conv"]
+    assert np.abs(np.array(outs["dot"]["x0"]) - np.array(d["x0"])).max() <= 1e-8 * d["nrm"]
