@@ -46,12 +46,13 @@ struct TileDesc { int start, nrows, pid, pad; };                       // 16 byt
 struct TileEntry8 {                                                  // short pattern: 256 bytes
   int len;
   int dslot;                                                         // index of the diagonal entry (offset 0), -1 without one
-  int pad0[6];
+  int uniform;                                                       // 1: the three components carry the same values (v[0] = v[1] = v[2] bit for bit)
+  int pad0[5];
   int delta[8];
   double v[3][8];
 };
 struct TileEntry16 {                                                 // long pattern: 512 bytes
-  int len, dslot, pad0[6];
+  int len, dslot, uniform, pad0[5];
   int delta[16];
   double v[3][16];
   int pad1[8];
@@ -164,14 +165,27 @@ __device__ inline void tile_rows_real(const TileDesc* __restrict__ desc, const E
     if (on[u]) {
       const long long row = (long long)d[u].start + 2 * lane;
       dbl2p sum; sum.x = 0.0; sum.y = 0.0;
+      const bool uni = e[u]->uniform != 0;                           // wave-uniform: a scalar branch
+      if (uni) {
+        // one value per entry for all three components (the interior of a uniform lattice): no per-lane selection -
+        // 4 v_cndmask per value and row pair less, a third of the kernel's vector instructions
 #pragma unroll
-      for (int i = 0; i < NL; ++i)
-        if (i < len[u]) {
-          const double v0 = e[u]->v[0][i], v1 = e[u]->v[1][i], v2 = e[u]->v[2][i];
-          const double va = ca == 0 ? v0 : (ca == 1 ? v1 : v2), vb = cb == 0 ? v0 : (cb == 1 ? v1 : v2);
-          sum.x = sum.x + va * xv[u][i].x;
-          sum.y = sum.y + vb * xv[u][i].y;
-        }
+        for (int i = 0; i < NL; ++i)
+          if (i < len[u]) {
+            const double v0 = e[u]->v[0][i];
+            sum.x = sum.x + v0 * xv[u][i].x;
+            sum.y = sum.y + v0 * xv[u][i].y;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+          if (i < len[u]) {
+            const double v0 = e[u]->v[0][i], v1 = e[u]->v[1][i], v2 = e[u]->v[2][i];
+            const double va = ca == 0 ? v0 : (ca == 1 ? v1 : v2), vb = cb == 0 ? v0 : (cb == 1 ? v1 : v2);
+            sum.x = sum.x + va * xv[u][i].x;
+            sum.y = sum.y + vb * xv[u][i].y;
+          }
+      }
       dbl2p o, rr;
       if (EPI == 0) {
         o = sum;
@@ -472,6 +486,7 @@ void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n
       });
     for (auto& th : pool) th.join();
   }
+  static const bool uniform_on = !(getenv("MXG_TILE_UNIFORM") && atoi(getenv("MXG_TILE_UNIFORM")) == 0);   // experiments
   std::unordered_map<std::string, int> idsA, idsB;
   std::vector<int32_t> irregular;
   std::string sg;
@@ -531,6 +546,7 @@ void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n
             te.delta[i] = (int32_t)((int64_t)ci[rp[r] + i] - r);
             for (int k = 0; k < 3; ++k) te.v[k][i] = va[rp[r + k] + i];
           }
+          te.uniform = uniform_on && std::memcmp(te.v[0], te.v[1], sizeof(te.v[0])) == 0 && std::memcmp(te.v[0], te.v[2], sizeof(te.v[0])) == 0;
           id = (int)P.dictB.size(); P.dictB.push_back(te);
         } else {
           TileEntry8 te{};
@@ -539,6 +555,7 @@ void tile_plan(const int64_t* rp, const int32_t* ci, const double* va, int64_t n
             te.delta[i] = (int32_t)((int64_t)ci[rp[r] + i] - r);
             for (int k = 0; k < 3; ++k) te.v[k][i] = va[rp[r + k] + i];
           }
+          te.uniform = uniform_on && std::memcmp(te.v[0], te.v[1], sizeof(te.v[0])) == 0 && std::memcmp(te.v[0], te.v[2], sizeof(te.v[0])) == 0;
           id = (int)P.dictA.size(); P.dictA.push_back(te);
         }
         ids.emplace(sg, id);
@@ -781,7 +798,7 @@ extern "C" int mxg_debug_tile_plan_apply(int64_t nrows, int64_t ncols_owned, con
       for (int t = 0; t < d.nrows; ++t) {
         const int64_t row = (int64_t)d.start + t;
         double s = 0.0;
-        for (int i = 0; i < e.len; ++i) s = s + e.v[t % 3][i] * x[row + e.delta[i]];
+        for (int i = 0; i < e.len; ++i) s = s + (e.uniform ? e.v[0][i] : e.v[t % 3][i]) * x[row + e.delta[i]];   // as the kernel picks its value
         dup += put(row, s, 0.0);
       }
     }
