@@ -1645,7 +1645,8 @@ int ell_prepare(mxg_ctx* c, mxg_csr* a) {
 }  // namespace
 
 int mxg_dev_csr_apply_ell(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y) {
-  if (x->k != 1 || y->k != 1 || x->base == y->base || (getenv("MXG_ELL") && atoi(getenv("MXG_ELL")) == 0)) return 1;
+  static const bool ell_off = getenv("MXG_ELL") && atoi(getenv("MXG_ELL")) == 0;     // read once: this runs per level per cycle
+  if (x->k != 1 || y->k != 1 || x->base == y->base || ell_off) return 1;
   if (ell_prepare(c, a) != 0) return 2;
   if (a->ell_state != 1) return 1;
   const unsigned grid = (unsigned)((a->nrows + 255) / 256);
@@ -1661,7 +1662,8 @@ int mxg_dev_csr_apply_ell(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y) {
 int mxg_dev_csr_apply_epi(mxg_ctx* c, mxg_csr* a, const mxg_mv* x, mxg_mv* y, int epi, const double* rhs,
                           const double* diag, double omega, double beta) {
   MXG_TRY(mxg_csr_materialize(const_cast<mxg_csr*>(a)));
-  if (epi == 3 && x->k == 1 && y->k == 1 && x->base != y->base && !(getenv("MXG_INJECT") && atoi(getenv("MXG_INJECT")) == 0)) {
+  static const bool inject_off = getenv("MXG_INJECT") && atoi(getenv("MXG_INJECT")) == 0;
+  if (epi == 3 && x->k == 1 && y->k == 1 && x->base != y->base && !inject_off) {
     if (inj_prepare(c, a) != 0) return 2;
     if (a->inj_state == 1) {
       const unsigned grid = (unsigned)((a->nrows + 255) / 256);
