@@ -70,12 +70,16 @@ class MxSolver {
     if (!sim->hasMu()) mEigProb->setM(rcp<OP>(new MxMassOp<Scalar>(mwOp->getRhs())));
     if (!mEigProb->setProblem() && myPID == 0)
       std::cout << "Anasazi::BasicEigenproblem::setProblem() returned with error." << std::endl;
-    if (type == "krylov-schur" || type == "davidson") {
-      // src/MxSolver.cpp:85-89: "davidson" selects Anasazi's BlockDavidson with locking; on the shift-inverted operator
-      // (no preconditioner of its own) it spans the same Krylov spaces, so the thick-restart block Krylov-Schur
-      // manager of this build serves both names and returns the same eigenpairs
+    if (type == "davidson" && hermitian && !ScalarTraits<Scalar>::isComplex) {
+      // src/MxSolver.cpp:88-91: Anasazi's BlockDavidson with locking, on the same operator and without a preconditioner
+      // of its own (the reference never calls setPrec): generalised Davidson expanding by the residuals
+      anasaziPList.set("Use Locking", true);
+      mEigMgr = rcp<Anasazi::SolverManager<Scalar, MV, OP> >(new Anasazi::BlockDavidsonSolMgr<Scalar, MV, OP>(mEigProb, anasaziPList));
+    } else if (type == "krylov-schur" || type == "davidson") {
+      // Anasazi's BlockDavidson takes Hermitian problems only (it throws otherwise): a dielectric / complex deck that
+      // asks for it is served by the block Krylov-Schur manager, with a notice
       if (type == "davidson" && myPID == 0 && verb)
-        std::cout << "MxSolver: eigensolver type 'davidson' -> block Krylov-Schur (same eigenpairs on the shift-inverted operator)\n";
+        std::cout << "MxSolver: eigensolver type 'davidson' needs a Hermitian problem -> block Krylov-Schur\n";
       mEigMgr = rcp<Anasazi::SolverManager<Scalar, MV, OP> >(new Anasazi::BlockKrylovSchurSolMgr<Scalar, MV, OP>(mEigProb, anasaziPList));
     } else {
       std::cout << "Unsupported eigensolver type: " << type << "\n";

@@ -140,6 +140,7 @@ typedef struct mxh_solver_params {
   uint64_t seed;
   const char* amg_smoother; /* "linear solver : amg : smoother": "Chebyshev" (default, src/MxProblem.cpp:56) | "Jacobi" */
   int amg_sweeps;           /* "linear solver : amg : sweeps" (default 2) */
+  const char* eig_type;     /* "eigensolver : type": "krylov-schur" (default) | "davidson" (src/MxSolver.cpp:85-94) */
 } mxh_solver_params;
 
 void mxh_solver_default_params(mxh_solver_params* p);

@@ -36,7 +36,7 @@ class SolverParamsC(C.Structure):
                 ("max_restarts", C.c_int), ("tol", C.c_double), ("shift", C.c_double),
                 ("lin_type", C.c_char_p), ("lin_basis", C.c_int), ("lin_tol", C.c_double),
                 ("prec_type", C.c_char_p), ("verbose", C.c_int), ("seed", C.c_uint64),
-                ("amg_smoother", C.c_char_p), ("amg_sweeps", C.c_int)]
+                ("amg_smoother", C.c_char_p), ("amg_sweeps", C.c_int), ("eig_type", C.c_char_p)]
 
 
 # name -> (restype, argtypes); the list doubles as the export check of the CPU test-suite

@@ -558,7 +558,7 @@ class SolverParams:
             self.set(k, v)
 
     def set(self, k, v):
-        if k in ("lin_type", "prec_type", "amg_smoother"):
+        if k in ("lin_type", "prec_type", "amg_smoother", "eig_type"):
             b = v.encode()
             self._keep.append(b)
             setattr(self.c, k, b)

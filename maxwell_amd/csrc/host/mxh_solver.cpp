@@ -15,6 +15,7 @@ extern "C" void mxh_solver_default_params(mxh_solver_params* p) {
   p->lin_type = "gmres"; p->lin_basis = 40; p->lin_tol = 1.0e-6; p->prec_type = "none";
   p->verbose = 0; p->seed = 12345;
   p->amg_smoother = "Chebyshev"; p->amg_sweeps = 2;      // src/MxProblem.cpp:56-57
+  p->eig_type = "krylov-schur";                          // src/MxProblem.cpp:28
 }
 
 void mxh_solver_build(mxh_solver& s, mxg_ctx* ctx, mxh_sim* sim, Teuchos::ParameterList const& pl) {
@@ -66,7 +67,7 @@ extern "C" int mxh_solver_create(mxg_ctx* ctx, mxh_sim* sim, const mxh_solver_pa
     s->linType = p->lin_type ? p->lin_type : "gmres";
     s->precType = p->prec_type ? p->prec_type : "none";
     Teuchos::ParameterList pl;
-    pl.set("eigensolver : type", "krylov-schur");
+    pl.set("eigensolver : type", p->eig_type ? p->eig_type : "krylov-schur");
     pl.set("eigensolver : nev", p->nev);
     pl.set("eigensolver : basis", p->basis);
     pl.set("eigensolver : block size", p->block_size);

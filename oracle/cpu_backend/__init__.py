@@ -45,13 +45,13 @@ def build(force=False):
     return OUT
 
 
-def eigen(n, nev=5, tol=1e-8, lin_tol=1e-9, threads=None, timeout=1200):
+def eigen(n, nev=5, tol=1e-8, lin_tol=1e-9, threads=None, timeout=1200, eig_type="krylov-schur"):
     """The product's eigen-solve of the pillbox at n^3 (same parameters as bench.py's GPU `eigen`) on the host cores."""
     build()
     env = dict(os.environ)
     if threads:
         env["OMP_NUM_THREADS"] = str(threads)
-    p = subprocess.run([sys.executable, os.path.join(HERE, "eigen_cpu.py"), str(n), str(nev), repr(tol), repr(lin_tol)],
+    p = subprocess.run([sys.executable, os.path.join(HERE, "eigen_cpu.py"), str(n), str(nev), repr(tol), repr(lin_tol), eig_type],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     if p.returncode != 0:
         raise RuntimeError("CPU backend eigen-solve failed: " + p.stderr.decode()[-2000:])

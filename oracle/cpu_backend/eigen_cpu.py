@@ -7,6 +7,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 n, nev, tol, lin_tol = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4])
+eig_type = sys.argv[5] if len(sys.argv) > 5 else "krylov-schur"
 json_fd = os.dup(1)
 os.dup2(2, 1)                                    # the solver's tables go to stderr, the JSON line to stdout
 import numpy as np
@@ -19,7 +20,7 @@ assert "CPU backend" in mx.CsrMatrix.from_scipy(ctx, __import__("scipy.sparse").
 t0 = time.perf_counter()
 sim = mx.Sim.pillbox(n)
 t1 = time.perf_counter()
-params = mx.SolverParams(nev=nev, basis=30, tol=tol, shift=0.05 * (2.0 * np.pi) ** 2, lin_type="cg", lin_tol=lin_tol, prec_type="amg")
+params = mx.SolverParams(nev=nev, basis=30, tol=tol, shift=0.05 * (2.0 * np.pi) ** 2, lin_type="cg", lin_tol=lin_tol, prec_type="amg", eig_type=eig_type)
 solver = mx.Solver(ctx, sim, params)
 t2 = time.perf_counter()
 nconv = solver.solve()

@@ -38,3 +38,20 @@ def test_cpu_backend_is_not_reachable_from_the_product():
     import os
     from maxwell_amd import _lib
     assert os.path.basename(_lib._LIBDIR) == "lib" and "oracle" not in _lib._LIBDIR
+
+
+def test_block_davidson_finds_the_same_modes(oracle_pillbox16):
+    """`eigensolver : type = davidson` (Anasazi::BlockDavidsonSolMgr with locking, src/MxSolver.cpp:88-91): the block
+    Davidson manager of AnasaziCompat.hpp on the host solver stack - the eigenvalues of the Krylov-Schur solve and of
+    the oracle's shift-invert of the same pencil."""
+    _, o = oracle_pillbox16
+    want = _oracle_physical_modes(o, yee.default_shift([1, 1, 1]), 5)
+    ks = cpu_backend.eigen(16, nev=5, tol=1e-10, lin_tol=1e-11, threads=4)
+    dv = cpu_backend.eigen(16, nev=5, tol=1e-10, lin_tol=1e-11, threads=4, eig_type="davidson")
+    assert dv["converged"] == 5
+    k2 = np.sort(dv["k2"])
+    assert np.abs(k2 - want).max() / np.abs(want).max() < 1e-8, (k2, want)
+    assert np.abs(k2 - np.sort(ks["k2"])).max() / np.abs(want).max() < 1e-8
+    assert dv["max_rel_residual"] < 1e-7
+    # no preconditioner of its own: the same Krylov spaces, about the same number of operator applications
+    assert dv["applies"] <= 2 * ks["applies"] + 10, (dv["applies"], ks["applies"])
