@@ -518,6 +518,7 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
     iters_ = 0;
     while (true) {
       bool breakdown = false;
+      int stable = 0;
       while (k - b < maxdim) {
         {
           std::unique_ptr<const MV> Vact(V->CloneView(range(k - b, b)));
@@ -541,6 +542,12 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
         setCols(*V, k, *W);
         k += b;
         if (rank < b) { breakdown = true; break; }
+        // convergence tested at every step once the first basis has been filled, as in the Hermitian path (solve())
+        {
+          static const int guard = getenv("MX_KS_GUARD") ? atoi(getenv("MX_KS_GUARD")) : 3;
+          if (restarts > 0 && k - b >= nev && k - b < maxdim && ritzConvergedGeneral(H, ldh, k - b, b, nev)) { if (++stable > guard) break; }
+          else stable = 0;
+        }
       }
       const int m = k - b;
       std::vector<double> A((size_t)m * m);
@@ -966,6 +973,30 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
         r2 += sum * sum;
       }
       if (!(std::sqrt(r2) <= tol_ * std::fabs(w[i]))) return false;
+    }
+    return true;
+  }
+
+  // the same for the general (non-Hermitian, real) recurrence: H holds the m x m block Hessenberg matrix and, in rows
+  // m .. m + b - 1, the coupling of the next block
+  bool ritzConvergedGeneral(const std::vector<double>& H, int ld, int m, int b, int nev) const {
+    typedef std::complex<double> C;
+    std::vector<double> A((size_t)m * m);
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) A[i + (size_t)m * j] = H[i + (size_t)ld * j];
+    std::vector<C> w, X;
+    if (!detail::genEig(m, A, w, X)) return false;
+    std::vector<int> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    sortRitzComplex(w, order);
+    for (int c = 0; c < nev; ++c) {
+      const int i = order[c];
+      double r2 = 0.0;
+      for (int r = 0; r < b; ++r) {
+        C sum(0.0);
+        for (int q = 0; q < b; ++q) sum += H[(m + r) + (size_t)ld * (m - b + q)] * X[(m - b + q) + (size_t)m * i];
+        r2 += std::norm(sum);
+      }
+      if (!(std::sqrt(r2) <= tol_ * std::abs(w[i]))) return false;
     }
     return true;
   }
