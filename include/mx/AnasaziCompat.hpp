@@ -731,6 +731,7 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
     iters_ = 0;
     while (true) {
       bool breakdown = false;
+      int stable = 0;
       while (k - b < maxdim) {
         {
           std::unique_ptr<const MV> Vact(V->CloneView(range(k - b, b)));
@@ -753,6 +754,12 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
         setCols(*V, k, *W);
         k += b;
         if (rank < b) { breakdown = true; break; }
+        // convergence tested at every step once the first basis has been filled, as in solve()
+        {
+          static const int guard = getenv("MX_KS_GUARD") ? atoi(getenv("MX_KS_GUARD")) : 3;
+          if (restarts > 0 && k - b >= nev && k - b < maxdim && ritzConvergedComplex(H, ldh, k - b, b, nev)) { if (++stable > guard) break; }
+          else stable = 0;
+        }
       }
       const int m = k - b;
       std::vector<C> A((size_t)m * m);
@@ -984,6 +991,28 @@ class BlockKrylovSchurSolMgr : public SolverManager<Scalar, MV, OP> {
     std::vector<double> A((size_t)m * m);
     for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) A[i + (size_t)m * j] = H[i + (size_t)ld * j];
     std::vector<C> w, X;
+    if (!detail::genEig(m, A, w, X)) return false;
+    std::vector<int> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    sortRitzComplex(w, order);
+    for (int c = 0; c < nev; ++c) {
+      const int i = order[c];
+      double r2 = 0.0;
+      for (int r = 0; r < b; ++r) {
+        C sum(0.0);
+        for (int q = 0; q < b; ++q) sum += H[(m + r) + (size_t)ld * (m - b + q)] * X[(m - b + q) + (size_t)m * i];
+        r2 += std::norm(sum);
+      }
+      if (!(std::sqrt(r2) <= tol_ * std::abs(w[i]))) return false;
+    }
+    return true;
+  }
+
+  // ... and for the complex recurrence
+  bool ritzConvergedComplex(const std::vector<std::complex<double> >& H, int ld, int m, int b, int nev) const {
+    typedef std::complex<double> C;
+    std::vector<C> A((size_t)m * m), w, X;
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) A[i + (size_t)m * j] = H[i + (size_t)ld * j];
     if (!detail::genEig(m, A, w, X)) return false;
     std::vector<int> order(m);
     std::iota(order.begin(), order.end(), 0);
