@@ -79,3 +79,24 @@ def test_pillbox32_analytic_modes(ctx):
     assert abs(k2[1] - te111) / te111 < 2e-3 and abs(k2[2] - te111) / te111 < 2e-3
     v = solver.eigvec(0, sim.map("bfield").size)
     assert np.all(v[sim.used_mask() == 0] == 0)       # unused components stay zero
+
+
+def test_block_davidson_on_the_gpu(ctx, oracle_pillbox12):
+    """`eigensolver : type = davidson` (src/MxSolver.cpp:88-91) through the C ABI on the device: the block Davidson
+    manager returns the eigenvalues of the Krylov-Schur solve and of the oracle's shift-invert of the same pencil, with
+    about as many operator applications (no preconditioner of its own: the same Krylov spaces)."""
+    _, o = oracle_pillbox12
+    shift = yee.default_shift([1, 1, 1])
+    want = _oracle_physical_modes(o, shift, 4)
+    sim = mx.Sim.pillbox(12)
+    out = {}
+    for eig_type in ("krylov-schur", "davidson"):
+        params = mx.SolverParams(nev=4, basis=20, tol=1e-10, shift=shift, lin_type="cg", lin_tol=1e-11, prec_type="jacobi",
+                                 block_size=2, eig_type=eig_type)
+        solver = mx.Solver(ctx, sim, params)
+        assert solver.solve() == 4
+        out[eig_type] = (np.sort([solver.result(i)["k2"].real for i in range(4)]), solver.stats()["applies"])
+        solver.close()
+    for eig_type, (k2, applies) in out.items():
+        assert np.abs(k2 - want).max() / np.abs(want).max() < REL_TOL, (eig_type, k2, want)
+    assert out["davidson"][1] <= 2 * out["krylov-schur"][1] + 10
