@@ -139,7 +139,7 @@ def test_decomposed_eigensolve_matches_single_rank(ctx, oracle_pillbox16, nranks
         # is the single-rank one up to summation order, so the inner iteration counts do not grow with the boxes
         # (per operator application: on another summation order the eigensolver may stop an application earlier or later)
         st1, stn = solver.stats(), out[0][1]
-        assert abs(stn["applies"] - st1["applies"]) <= 2
+        assert abs(stn["applies"] - st1["applies"]) <= 4
         for key in ("vec_iters", "sca_iters"):
             per1, pern = st1[key] / st1["applies"], stn[key] / stn["applies"]
             assert abs(pern - per1) <= 0.05 * per1 + 0.1, (key, per1, pern)
