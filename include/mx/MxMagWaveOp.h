@@ -364,7 +364,7 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
     mOpts.tol = linTol;
     mOpts.restart = linBasis;
     mOpts.max_iters = mPList.get("linear solver : max iters", 0);
-    mOpts.cheb_degree = 0; mOpts.lmin = 0; mOpts.lmax = 0; mOpts.mg = nullptr;
+    mOpts.flags = 0; mOpts.lmin = 0; mOpts.lmax = 0; mOpts.mg = nullptr;
     if (mUseMg) buildMultigrid((Scalar*)0);
   }
 
@@ -451,8 +451,10 @@ class MxMagWaveOp : public Anasazi::Operator<Scalar> {
 
   mxg_mg* vecMgHandle() const { return mVecDmg ? mVecDmg->handle() : (mVecMg ? mxh_mg_handle(mVecMg) : nullptr); }
   mxg_mg* scaMgHandle() const { return mScaDmg ? mScaDmg->handle() : (mScaMg ? mxh_mg_handle(mScaMg) : nullptr); }
+  // (every solve of Apply starts from x = 0, set just before the call: the library takes b as the initial residual)
   int solve(mxg_ctx* ctx, mxg_csr* A, mxg_mv* b, mxg_mv* x, mxg_solve_info* info, mxg_mg* mg) const {
     mxg_solve_opts o = mOpts;
+    o.flags |= MXG_SOLVE_ZERO_GUESS;
     o.mg = (mUseMg && mg) ? mg : nullptr;
     if (o.precond == 3 && !o.mg) o.precond = 1;
     if (mUseBicg) return mxg_solve_bicgstab(ctx, A, b, x, &o, info);

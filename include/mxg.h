@@ -241,12 +241,13 @@ int mxg_mg_apply(mxg_ctx* ctx, mxg_mg* mg, const mxg_mv* r, mxg_mv* z);
  * imports of every sweep on every level below (they are latency-bound there).  `tail` stays owned by the caller. */
 int mxg_mg_set_tail(mxg_mg* mg, mxg_mg* tail, const int64_t* counts);
 
+#define MXG_SOLVE_ZERO_GUESS 1
 typedef struct mxg_solve_opts {
   double tol;          /* unscaled true-residual 2-norm target (AZ_noscaled, :346,352) */
   int restart;         /* Krylov subspace (AZ_kspace, "linear solver : basis") */
   int max_iters;       /* total iteration cap; 0 = library default */
   int precond;         /* 0 none, 1 Jacobi (diagonal), 3 multigrid V-cycle (`mg`) */
-  int cheb_degree;     /* reserved */
+  int flags;           /* bit 0 (MXG_SOLVE_ZERO_GUESS): x is zero on entry - the initial residual is b, no product with A */
   double lmin, lmax;   /* reserved */
   mxg_mg* mg;          /* hierarchy for precond == 3 (not owned) */
 } mxg_solve_opts;

@@ -23,7 +23,7 @@ class HaloPlan(C.Structure):
 
 class SolveOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("restart", C.c_int), ("max_iters", C.c_int),
-                ("precond", C.c_int), ("cheb_degree", C.c_int),
+                ("precond", C.c_int), ("flags", C.c_int),
                 ("lmin", C.c_double), ("lmax", C.c_double), ("mg", C.c_void_p)]
 
 

@@ -44,6 +44,12 @@ inline int true_residual(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, const mx
   MXK_TRY(mxg_mv_axpby(1.0, 0.0, b, -1.0, 0.0, r));   // r = b - A x
   return mxg_mv_norm2(r, nrm);
 }
+// the residual of the initial guess; with MXG_SOLVE_ZERO_GUESS it is b itself (b - A 0 = b to the bit: no product)
+inline int initial_residual(mxg_ctx* c, const mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, const mxg_mv* x, mxg_mv* r, double* nrm) {
+  if (!(o->flags & MXG_SOLVE_ZERO_GUESS)) return true_residual(c, A, b, x, r, nrm);
+  MXK_TRY(mxg_mv_copy(r, b));
+  return mxg_mv_norm2(r, nrm);
+}
 
 struct Shape { int64_t nrows = 0; int cx = 0, k = 0; };
 inline int shape_of(const mxg_csr* A, const mxg_mv* b, Shape* s) {
@@ -83,7 +89,7 @@ int solve_cg(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x, const mxg
       if (res > o->tol) info->converged = 0;
       continue;
     }
-    MXK_TRY(true_residual(c, A, bj, xj, r, &res));
+    MXK_TRY(initial_residual(c, A, o, bj, xj, r, &res));
     // outer loop = the reference's `while (trueRes > linTol)` (src/MxMagWaveOp.cpp:876-885)
     while (res > o->tol && it < max_iters) {
       MXK_TRY(apply_prec(r, z));
@@ -144,7 +150,7 @@ int solve_bicgstab(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x, con
     MXK_TRY(g.view(const_cast<mxg_mv*>(b), col, 1, &bj));
     MXK_TRY(g.view(x, col, 1, &xj));
     double res = 0.0;
-    MXK_TRY(true_residual(c, A, bj, xj, r, &res));
+    MXK_TRY(initial_residual(c, A, o, bj, xj, r, &res));
     int it = 0;
     while (res > o->tol && it < max_iters) {       // (re)start from the true residual
       MXK_TRY(mxg_mv_copy(rh, r));
@@ -229,7 +235,7 @@ int solve_gmres(mxg_ctx* c, const mxg_csr* A, const mxg_mv* b, mxg_mv* x, const 
     MXK_TRY(g.view(const_cast<mxg_mv*>(b), col, 1, &bj));
     MXK_TRY(g.view(x, col, 1, &xj));
     double res = 0.0;
-    MXK_TRY(true_residual(c, A, bj, xj, r, &res));
+    MXK_TRY(initial_residual(c, A, o, bj, xj, r, &res));
     int it = 0;
     while (res > o->tol && it < max_iters) {
       // one restart cycle (right preconditioned: A M^-1 u = b, x = M^-1 u)

@@ -19,6 +19,7 @@
 namespace {
 
 using mxg_krylov::true_residual;
+using mxg_krylov::initial_residual;
 
 __global__ void k_jacobi(const double* __restrict__ diag, int w, long long n,
                          const double* __restrict__ r, double* __restrict__ z) {
@@ -648,7 +649,7 @@ int cg_fused(mxg_ctx* c, mxg_csr* A, const mxg_solve_opts* o, const mxg_mv* b, m
     return mxg_comm_on(c) ? mxg_comm_allreduce(c, ptr, (size_t)count, c->stream) : 0;
   };
   double res = 0.0;
-  MXG_TRY(true_residual(c, A, b, x, r, &res));
+  MXG_TRY(initial_residual(c, A, o, b, x, r, &res));
   int it = 0;
   mxg_mv* zc = z;                        // where the preconditioned residual sits (multigrid: its own level-0 vector)
   // z = V-cycle(r) (in the hierarchy's own vector: -4.6 % at 256^3 against two copies) and r.z into slot `slot`
